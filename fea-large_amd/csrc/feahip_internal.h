@@ -1,0 +1,115 @@
+// feahip_internal.h -- context layout shared by the translation units of
+// libfeahip.so.  Not part of the ABI (include/fea_hip.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include "../../include/fea_hip.h"
+
+#define FEA_MAX_NPE 10
+#define FEA_MAX_GAUSS 27
+
+// one wave owns a run of block rows ("chunk"); its 3x3 blocks are summed in
+// LDS and written to HBM once.  CHUNK_BLOCKS bounds the LDS per wave.
+#define FEA_CHUNK_BLOCKS 128
+#define FEA_CHUNK_ROWS 16
+#define FEA_WAVES_PER_WG 4
+// grid used by the vector / reduction kernels: their per-block partial sums
+// are re-reduced by every block of the consuming kernel.
+#define FEA_RED_BLOCKS 1024
+
+struct ElemTable {            // element plug-in, tabulated by the host
+  double w[FEA_MAX_GAUSS];
+  double dN[FEA_MAX_GAUSS][3][FEA_MAX_NPE];
+};
+
+struct feahip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // sizes
+  int N = 0, E = 0, npe = 0, G = 0, ndof = 0;
+  int nnzb = 0;               // 3x3 blocks in the full symmetric pattern
+  int nchunks = 0;
+  int max_rowlen = 0;
+  bool linear_tet = false;    // npe == 4 and dN is the constant-strain table
+  int model = 0;
+  double lambda = 0, mu = 0;
+  int strategy = FEAHIP_ASM_AUTO;
+
+  ElemTable table;
+  ElemTable *d_table = nullptr;
+
+  // mesh (device)
+  int *d_conn = nullptr;       // [E][npe]
+  double *d_X0 = nullptr;      // [N][4] padded to 32 B (two dwordx4 per node)
+  double *d_x = nullptr;       // [N][4] current configuration
+  // block-CSR pattern of K (built once; topology never changes)
+  int *d_rowptr = nullptr;     // [N+1]
+  int *d_colidx = nullptr;     // [nnzb]
+  double *d_K = nullptr;       // [nnzb][3][3]
+  double *d_Kstash = nullptr;  // modified-Newton copy (fea_solver.c:179)
+  bool have_stash = false;
+  // node -> element incidence (row-owner assembly)
+  int *d_incptr = nullptr;     // [N+1]
+  uint32_t *d_inc = nullptr;   // [npe*E]  elem | local<<28
+  uint8_t *d_incslot = nullptr;// [npe*E][npe] slot of column conn[e][b] in row
+  int *d_chunk = nullptr;      // [nchunks+1] first row of every chunk
+  // vectors (3N doubles)
+  double *d_f = nullptr, *d_u = nullptr;
+  double *d_r = nullptr, *d_p = nullptr, *d_q = nullptr, *d_minv = nullptr;
+  double *d_part = nullptr;    // reduction partials, 4 x FEA_RED_BLOCKS
+  double *d_scal = nullptr;    // device scalars of the CG recurrences
+  int *d_flag = nullptr;       // [0] converged-at iteration, [1] bad Gauss pts
+  // prescribed displacements
+  int n_presc = 0;             // nodes in the deck
+  int n_cdof = 0;              // constrained dofs, deck order x,y,z per node
+  int *d_cdof = nullptr;
+  double *d_cval = nullptr;    // prescribed value per constrained dof
+  uint8_t *d_dofmask = nullptr;// [3N] 1 = constrained
+  // cached per-Gauss-point state for the getters
+  double *d_F = nullptr, *d_S = nullptr;   // [E][G][9]
+  bool state_valid = false;
+
+  // host copies needed by getters / pattern export
+  std::vector<int> h_rowptr, h_colidx;
+  long long aux_bytes = 0;
+
+  int last_bad = 0;
+};
+
+#define FEA_HIP_CHECK(ctx, call)                                            \
+  do {                                                                      \
+    hipError_t _e = (call);                                                 \
+    if (_e != hipSuccess) {                                                 \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(_e);       \
+      return FEAHIP_EHIP;                                                   \
+    }                                                                       \
+  } while (0)
+
+// pattern.cpp
+struct HostPattern {
+  std::vector<int> rowptr, colidx;       // block CSR, sorted columns
+  std::vector<int> incptr;               // [N+1]
+  std::vector<uint32_t> inc;             // [npe*E]
+  std::vector<uint8_t> incslot;          // [npe*E*npe]
+  std::vector<int> chunk;                // chunk -> first row
+  int max_rowlen = 0;
+};
+int build_host_pattern(int N, int E, int npe, const int *conn, HostPattern &hp,
+                       std::string &err);
+
+// launchers (kernels_assemble.hip / kernels_solve.hip)
+int launch_assemble(feahip_ctx *c, bool doK, bool doF);
+int launch_state_export(feahip_ctx *c);
+int launch_apply_bc(feahip_ctx *c, double lambda);
+int launch_update_nodes_bc(feahip_ctx *c, double lambda);
+int launch_update_nodes_solution(feahip_ctx *c, const double *d_u);
+int launch_spmv(feahip_ctx *c, const double *d_xv, double *d_yv);
+int solve_pcg(feahip_ctx *c, int type, double tol, int max_iter, int *iters,
+              double *resid);
+int launch_dot(feahip_ctx *c, const double *a, const double *b, double *out_host);
+int time_pcg_iteration(feahip_ctx *c, int warmup, int iters, double *avg_ms);

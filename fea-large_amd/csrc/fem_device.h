@@ -1,0 +1,226 @@
+// fem_device.h -- per-Gauss-point device math of the hot path.
+//
+// What the reference evaluates in four separate sweeps over heap objects --
+//   J, J^-1, grad N      solver_shape_gradients_alloc   fea_solver.c:656-722
+//   F^-1 -> F            solver_element_gauss_graddef   fea_solver.c:1131-1152
+//   sigma(F)             fea_model_stress_*             fea_model.c:26-107
+//   c(F)                 fea_model_ctensor_*            fea_model.c:110-148
+// is evaluated here in registers, once per (element, Gauss point) visit.
+//
+// The spatial tangent enters the stiffness only through its minor-symmetrised
+// form (fea_solver.c:948-949), which for both models collapses to
+//   c~_ikjl = l1 d_ik d_jl + m1 (d_ij d_kl + d_il d_kj)
+// with  l1 = lambda/J, m1 = (mu - lambda ln J)/J   (Neo-Hookean, :138-146)
+//       l1 = lambda/J, m1 = mu/J                   (A5, :116-126)
+// so one 3x3 block of the element stiffness is
+//   K_ab = w|detJ| [ l1 g_a (x) g_b + m1 g_b (x) g_a
+//                    + (m1 g_a.g_b + g_a.sigma.g_b) I ]          (:944-1049)
+// about 25 FMAs instead of the reference's 2 x 81-term loops.
+#pragma once
+#include "feahip_internal.h"
+
+struct AsmArgs {
+  int N, E, G, nchunks, model;
+  double lambda, mu;
+  const ElemTable *tab;
+  const int *conn;
+  const double *X0, *x;          // [N][4]
+  const int *rowptr, *colidx;
+  double *K;
+  double *f;
+  const int *incptr;
+  const uint32_t *inc;
+  const uint8_t *incslot;
+  const int *chunk;
+  int *bad;                      // counter of Gauss points with det J <= 0
+  double *Fout, *Sout;           // state export
+};
+
+template <int NPE>
+struct GPState {
+  double g[NPE][3];    // spatial shape gradients  g[a][i] = dN_a/dx_i
+  double sig[3][3];    // Cauchy stress
+  double l1, m1;       // tangent coefficients (see header)
+  double vol;          // w_g * |det J|
+  double detJ;
+  double F[3][3];
+};
+
+__device__ __forceinline__ double fd_det3(const double m[3][3])
+{
+  return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) -
+         m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+         m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+}
+
+// adjugate / det (dense_matrix.c:34-60 divides nine times; one reciprocal
+// here, the difference is 1 ulp per entry)
+__device__ __forceinline__ void fd_inv3(const double m[3][3], double r[3][3], double &det)
+{
+  det = fd_det3(m);
+  double id = 1.0 / det;
+  r[0][0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) * id;
+  r[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) * id;
+  r[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) * id;
+  r[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) * id;
+  r[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) * id;
+  r[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) * id;
+  r[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) * id;
+  r[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) * id;
+  r[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) * id;
+}
+
+// State of one Gauss point from the element's current (xe) and initial (Xe)
+// node coordinates.  LINTET: constant-strain tetrahedron, dN/dxi is the
+// fixed table {-1,1,0,0; -1,0,1,0; -1,0,0,1} and is folded into the algebra.
+template <int NPE, bool LINTET>
+__device__ __forceinline__ void gp_state(const double (&xe)[NPE][3], const double (&Xe)[NPE][3],
+                                         const ElemTable *tab, int gp, int model,
+                                         double lambda, double mu, GPState<NPE> &s)
+{
+  double J[3][3], Ji[3][3];
+  if constexpr (LINTET) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) J[i][j] = xe[i + 1][j] - xe[0][j];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        double acc = 0;
+#pragma unroll
+        for (int k = 0; k < NPE; ++k) acc += tab->dN[gp][i][k] * xe[k][j];
+        J[i][j] = acc;
+      }
+  }
+  fd_inv3(J, Ji, s.detJ);
+  if constexpr (LINTET) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      s.g[1][i] = Ji[i][0]; s.g[2][i] = Ji[i][1]; s.g[3][i] = Ji[i][2];
+      s.g[0][i] = -(Ji[i][0] + Ji[i][1] + Ji[i][2]);
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < NPE; ++a)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        double acc = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc += Ji[i][k] * tab->dN[gp][k][a];
+        s.g[a][i] = acc;
+      }
+  }
+  // F^-1_ij = sum_k dN_k/dx_j X_k,i  (fea_solver.c:1141-1151), then invert
+  double Fi[3][3], detFi;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double acc = 0;
+      if constexpr (LINTET) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) acc += s.g[k][j] * (Xe[k][i] - Xe[0][i]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < NPE; ++k) acc += s.g[k][j] * Xe[k][i];
+      }
+      Fi[i][j] = acc;
+    }
+  fd_inv3(Fi, s.F, detFi);
+  const double Jd = fd_det3(s.F);
+  const double iJ = 1.0 / Jd;
+  if (model == FEAHIP_MODEL_COMPRESSIBLE_NEOHOOKEAN) {
+    const double lnJ = log(Jd);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        double b = s.F[i][0] * s.F[j][0] + s.F[i][1] * s.F[j][1] + s.F[i][2] * s.F[j][2];
+        double d = (i == j) ? 1.0 : 0.0;
+        s.sig[i][j] = (mu * (b - d) + lambda * lnJ * d) * iJ;
+      }
+    s.l1 = lambda * iJ;
+    s.m1 = (mu - lambda * lnJ) * iJ;
+  } else {
+    // A5: S = (lambda tr(C) I + 2 mu C)/J, C = (F'F - I)/2, sigma = F S F'
+    double Sn[3][3], T[3][3], I1 = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        double gij = s.F[0][i] * s.F[0][j] + s.F[1][i] * s.F[1][j] + s.F[2][i] * s.F[2][j];
+        Sn[i][j] = 0.5 * (gij - ((i == j) ? 1.0 : 0.0));
+      }
+    I1 = Sn[0][0] + Sn[1][1] + Sn[2][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        Sn[i][j] = (lambda * I1 * ((i == j) ? 1.0 : 0.0) + 2 * mu * Sn[i][j]) * iJ;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        T[i][j] = s.F[i][0] * Sn[0][j] + s.F[i][1] * Sn[1][j] + s.F[i][2] * Sn[2][j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        s.sig[i][j] = T[i][0] * s.F[j][0] + T[i][1] * s.F[j][1] + T[i][2] * s.F[j][2];
+    s.l1 = lambda * iJ;
+    s.m1 = mu * iJ;
+  }
+  s.vol = tab->w[gp] * fabs(s.detJ);
+}
+
+// column-node vectors of a block: h = vol l1 g_b, m = vol m1 g_b,
+// t = m + vol sigma g_b
+__device__ __forceinline__ void col_vectors(const double gb[3], const double sig[3][3],
+                                            double l1, double m1, double vol,
+                                            double h[3], double m[3], double t[3])
+{
+  const double vl = vol * l1, vm = vol * m1;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    h[k] = vl * gb[k];
+    m[k] = vm * gb[k];
+    t[k] = m[k] + vol * (sig[k][0] * gb[0] + sig[k][1] * gb[1] + sig[k][2] * gb[2]);
+  }
+}
+
+// K_ab (row-major 3x3) from the row-node gradient and the column vectors
+__device__ __forceinline__ void block_ab(const double ga[3], const double h[3], const double m[3],
+                                         const double t[3], double out[9])
+{
+  const double d = ga[0] * t[0] + ga[1] * t[1] + ga[2] * t[2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      out[3 * i + j] = ga[i] * h[j] + ga[j] * m[i] + ((i == j) ? d : 0.0);
+}
+
+template <int NPE>
+__device__ __forceinline__ void load_element(const AsmArgs &A, int e, int (&nd)[NPE],
+                                             double (&xe)[NPE][3], double (&Xe)[NPE][3])
+{
+  if constexpr (NPE == 4) {
+    const int4 c = *reinterpret_cast<const int4 *>(A.conn + (size_t)e * 4);
+    nd[0] = c.x; nd[1] = c.y; nd[2] = c.z; nd[3] = c.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < NPE; ++k) nd[k] = A.conn[(size_t)e * NPE + k];
+  }
+#pragma unroll
+  for (int k = 0; k < NPE; ++k) {
+    const double2 a0 = *reinterpret_cast<const double2 *>(A.x + (size_t)nd[k] * 4);
+    const double2 a1 = *reinterpret_cast<const double2 *>(A.x + (size_t)nd[k] * 4 + 2);
+    const double2 b0 = *reinterpret_cast<const double2 *>(A.X0 + (size_t)nd[k] * 4);
+    const double2 b1 = *reinterpret_cast<const double2 *>(A.X0 + (size_t)nd[k] * 4 + 2);
+    xe[k][0] = a0.x; xe[k][1] = a0.y; xe[k][2] = a1.x;
+    Xe[k][0] = b0.x; Xe[k][1] = b0.y; Xe[k][2] = b1.x;
+  }
+}

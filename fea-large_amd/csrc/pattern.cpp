@@ -1,0 +1,126 @@
+// pattern.cpp -- one-time host construction of the sparsity pattern and the
+// node->element incidence maps from the element->node map.
+//
+// The reference grows its matrix dynamically inside sp_matrix_element_add
+// (fea_solver.c:966,1055) and converts it to Yale form before every solve
+// (:304).  The mesh topology never changes, so here the full symmetric
+// block pattern is built once: block row a holds one 3x3 block per node that
+// shares an element with node a, columns sorted ascending (which is the
+// column order sp_matrix_yale has).
+#include "feahip_internal.h"
+#include <algorithm>
+#include <thread>
+
+namespace {
+
+template <class F>
+void parallel_ranges(int n, F f)
+{
+  unsigned hw = std::thread::hardware_concurrency();
+  int nt = (int)std::min<unsigned>(hw ? hw : 4, 32);
+  if (n < 65536) nt = 1;
+  if (nt <= 1) { f(0, n, 0); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t) {
+    int lo = (int)((long long)n * t / nt), hi = (int)((long long)n * (t + 1) / nt);
+    th.emplace_back([=] { f(lo, hi, t); });
+  }
+  for (auto &x : th) x.join();
+}
+
+}  // namespace
+
+int build_host_pattern(int N, int E, int npe, const int *conn, HostPattern &hp,
+                       std::string &err)
+{
+  if (E >= (1 << 28)) { err = "too many elements for the packed incidence word"; return FEAHIP_EINVAL; }
+  for (long long i = 0; i < (long long)E * npe; ++i)
+    if (conn[i] < 0 || conn[i] >= N) {
+      err = "element " + std::to_string(i / npe) + " refers to node " +
+            std::to_string(conn[i]) + " outside [0," + std::to_string(N) + ")";
+      return FEAHIP_EINVAL;
+    }
+
+  // node -> element incidence, elements ascending inside every node
+  hp.incptr.assign((size_t)N + 1, 0);
+  for (long long i = 0; i < (long long)E * npe; ++i) hp.incptr[conn[i] + 1]++;
+  for (int a = 0; a < N; ++a) hp.incptr[a + 1] += hp.incptr[a];
+  hp.inc.resize((size_t)E * npe);
+  {
+    std::vector<int> fill(hp.incptr.begin(), hp.incptr.end() - 1);
+    for (int e = 0; e < E; ++e)
+      for (int k = 0; k < npe; ++k) {
+        int a = conn[(size_t)e * npe + k];
+        hp.inc[fill[a]++] = (uint32_t)e | ((uint32_t)k << 28);
+      }
+  }
+
+  // neighbour sets -> block rows
+  hp.rowptr.assign((size_t)N + 1, 0);
+  auto row_nodes = [&](int a, std::vector<int> &tmp) {
+    tmp.clear();
+    for (int p = hp.incptr[a]; p < hp.incptr[a + 1]; ++p) {
+      int e = (int)(hp.inc[p] & 0x0FFFFFFFu);
+      for (int k = 0; k < npe; ++k) tmp.push_back(conn[(size_t)e * npe + k]);
+    }
+    if (tmp.empty()) tmp.push_back(a);   // isolated node keeps its diagonal
+    std::sort(tmp.begin(), tmp.end());
+    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+  };
+  parallel_ranges(N, [&](int lo, int hi, int) {
+    std::vector<int> tmp;
+    for (int a = lo; a < hi; ++a) { row_nodes(a, tmp); hp.rowptr[a + 1] = (int)tmp.size(); }
+  });
+  long long tot = 0;
+  int maxlen = 0;
+  for (int a = 0; a < N; ++a) {
+    maxlen = std::max(maxlen, hp.rowptr[a + 1]);
+    tot += hp.rowptr[a + 1];
+    if (tot > 0x7FFFFFFFLL / 9) { err = "pattern exceeds 32-bit block indexing"; return FEAHIP_EINVAL; }
+    hp.rowptr[a + 1] = (int)tot;
+  }
+  hp.max_rowlen = maxlen;
+  hp.colidx.resize((size_t)tot);
+  parallel_ranges(N, [&](int lo, int hi, int) {
+    std::vector<int> tmp;
+    for (int a = lo; a < hi; ++a) {
+      row_nodes(a, tmp);
+      std::copy(tmp.begin(), tmp.end(), hp.colidx.begin() + hp.rowptr[a]);
+    }
+  });
+
+  // slot of every (incidence, local column node) inside its block row
+  if (maxlen <= 255) {
+    hp.incslot.resize((size_t)E * npe * npe);
+    parallel_ranges(N, [&](int lo, int hi, int) {
+      for (int a = lo; a < hi; ++a) {
+        const int *cb = hp.colidx.data() + hp.rowptr[a];
+        const int *ce = hp.colidx.data() + hp.rowptr[a + 1];
+        for (int p = hp.incptr[a]; p < hp.incptr[a + 1]; ++p) {
+          int e = (int)(hp.inc[p] & 0x0FFFFFFFu);
+          for (int k = 0; k < npe; ++k) {
+            int b = conn[(size_t)e * npe + k];
+            hp.incslot[(size_t)p * npe + k] = (uint8_t)(std::lower_bound(cb, ce, b) - cb);
+          }
+        }
+      }
+    });
+  } else {
+    hp.incslot.clear();   // row-owner assembly unavailable; atomic path only
+  }
+
+  // chunks of consecutive rows, each small enough for one wave's LDS tile
+  hp.chunk.clear();
+  hp.chunk.push_back(0);
+  int rows = 0, blocks = 0;
+  for (int a = 0; a < N; ++a) {
+    int len = hp.rowptr[a + 1] - hp.rowptr[a];
+    if (rows > 0 && (rows == FEA_CHUNK_ROWS || blocks + len > FEA_CHUNK_BLOCKS)) {
+      hp.chunk.push_back(a);
+      rows = 0; blocks = 0;
+    }
+    rows++; blocks += len;
+  }
+  hp.chunk.push_back(N);
+  return FEAHIP_OK;
+}

@@ -1,0 +1,389 @@
+"""ctypes mirror of include/fea_hip.h and host/fea_host.h.
+
+Python is plumbing here (tests, bench): every call goes straight through the
+C ABI of libfeahip.so -- the same symbols a C host (the reference's solve(),
+solver-large/fea_solver.c:130-242) binds.  There is no Python or CPU
+implementation behind these names: if the shared library is missing, or no
+HIP device is visible, construction fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfeahip.so")
+HOST_LIB_PATH = os.path.join(_HERE, "libfeahost.so")
+
+MODEL_A5, MODEL_COMPRESSIBLE_NEOHOOKEAN = 0, 1
+CG, PCG_ILU, CHOLESKY = 0, 1, 2
+ASM_AUTO, ASM_ROWOWNER, ASM_ATOMIC = 0, 1, 2
+TETRAHEDRA10, TETRAHEDRA4 = 0, 1
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+# every symbol include/fea_hip.h declares, with its argument types
+ABI = {
+    "feahip_create": [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _ip, _dp,
+                      C.c_int, _dp, C.c_int, C.c_int, _ip, _ip, _dp],
+    "feahip_destroy": [C.c_void_p],
+    "feahip_last_error": [C.c_void_p],
+    "feahip_create_error": [],
+    "feahip_update_nodes_with_bc": [C.c_void_p, C.c_double],
+    "feahip_update_state": [C.c_void_p, _ip],
+    "feahip_create_stiffness": [C.c_void_p],
+    "feahip_create_residual_forces": [C.c_void_p],
+    "feahip_create_stiffness_and_residual": [C.c_void_p],
+    "feahip_stash_stiffness": [C.c_void_p],
+    "feahip_restore_stiffness": [C.c_void_p],
+    "feahip_apply_prescribed_bc": [C.c_void_p, C.c_double],
+    "feahip_solve_slae": [C.c_void_p, C.c_int, C.c_double, C.c_int, _ip, _dp],
+    "feahip_energy": [C.c_void_p, _dp],
+    "feahip_update_nodes_with_solution": [C.c_void_p, _dp],
+    "feahip_solve": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, _dp,
+                     C.c_int, _ip, _ip],
+    "feahip_set_nodes": [C.c_void_p, _dp],
+    "feahip_get_nodes": [C.c_void_p, _dp],
+    "feahip_get_forces": [C.c_void_p, _dp],
+    "feahip_set_forces": [C.c_void_p, _dp],
+    "feahip_get_solution": [C.c_void_p, _dp],
+    "feahip_get_graddefs": [C.c_void_p, _dp],
+    "feahip_get_stresses": [C.c_void_p, _dp],
+    "feahip_matrix_nnz": [C.c_void_p, C.POINTER(C.c_longlong)],
+    "feahip_get_matrix_yale": [C.c_void_p, _ip, _ip, _dp],
+    "feahip_spmv": [C.c_void_p, _dp, _dp],
+    "feahip_set_assembly": [C.c_void_p, C.c_int],
+    "feahip_sync": [C.c_void_p],
+    "feahip_time_kernel": [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp],
+    "feahip_sizes": [C.c_void_p, C.POINTER(C.c_longlong)],
+}
+
+_lib = None
+_host = None
+
+
+class FeaHipError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen libfeahip.so and type every ABI symbol (no device is touched)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FeaHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`; "
+                "there is no fallback implementation")
+        lib = C.CDLL(LIB_PATH)
+        for name, args in ABI.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is absent
+            fn.argtypes = args
+            fn.restype = C.c_char_p if name in ("feahip_last_error", "feahip_create_error") else (
+                None if name == "feahip_destroy" else C.c_int)
+        _lib = lib
+    return _lib
+
+
+class FeaDeck(C.Structure):
+    """struct fea_deck of host/fea_host.h."""
+    _fields_ = [
+        ("model", C.c_int), ("parameters", C.c_double * 10), ("parameters_count", C.c_int),
+        ("solver_type", C.c_int), ("solver_tolerance", C.c_double), ("solver_max_iter", C.c_int),
+        ("ele_type", C.c_int), ("load_increments_count", C.c_int), ("desired_tolerance", C.c_double),
+        ("max_newton_count", C.c_int), ("linesearch_max", C.c_int), ("arclength_max", C.c_int),
+        ("modified_newton", C.c_int), ("nodes_per_element", C.c_int), ("gauss_nodes_count", C.c_int),
+        ("nodes_count", C.c_int), ("nodes", _dp), ("elements_count", C.c_int), ("elements", _ip),
+        ("prescribed_nodes_count", C.c_int), ("presc_node", _ip), ("presc_type", _ip), ("presc_values", _dp),
+    ]
+
+
+def load_host_library():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise FeaHipError(f"{HOST_LIB_PATH} is missing: run __graft_entry__.build()")
+        load_library()   # libfeahost.so links against libfeahip.so
+        h = C.CDLL(HOST_LIB_PATH)
+        h.fea_deck_load.argtypes = [C.c_char_p, C.POINTER(FeaDeck), C.c_char_p, C.c_int]
+        h.fea_deck_load.restype = C.c_int
+        h.fea_deck_free.argtypes = [C.POINTER(FeaDeck)]
+        h.fea_deck_free.restype = None
+        h.fea_deck_save.argtypes = [C.c_char_p, C.POINTER(FeaDeck)]
+        h.fea_deck_save.restype = C.c_int
+        h.fea_element_tables.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
+        h.fea_element_tables.restype = C.c_int
+        h.fea_deck_create_solver.argtypes = [C.POINTER(FeaDeck), C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_int]
+        h.fea_deck_create_solver.restype = C.c_int
+        h.fea_solve.argtypes = [C.POINTER(FeaDeck), C.c_void_p, C.c_void_p, _dp, C.c_int]
+        h.fea_solve.restype = C.c_int
+        _host = h
+    return _host
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def element_tables(ele_type, gauss_count):
+    """(weights[G], forms[G][npe], dforms[G][3][npe]) from the host plug-in."""
+    h = load_host_library()
+    npe = 10 if ele_type == TETRAHEDRA10 else 4
+    w = np.zeros(gauss_count)
+    forms = np.zeros((gauss_count, npe))
+    dforms = np.zeros((gauss_count, 3, npe))
+    rc = h.fea_element_tables(ele_type, gauss_count, _d(w), _d(forms), _d(dforms))
+    if rc < 0:
+        raise FeaHipError(f"unsupported element type {ele_type} with {gauss_count} Gauss points")
+    return w, forms, dforms
+
+
+class Deck:
+    """A task deck as numpy arrays (fields named as the reference's structs)."""
+
+    def __init__(self, **kw):
+        self.model = kw.get("model", MODEL_COMPRESSIBLE_NEOHOOKEAN)
+        self.parameters = np.array(kw.get("parameters", [100.0, 100.0]), dtype=np.float64)
+        self.solver_type = kw.get("solver_type", CG)
+        self.solver_tolerance = kw.get("solver_tolerance", 1e-14)
+        self.solver_max_iter = kw.get("solver_max_iter", 20000)
+        self.ele_type = kw.get("ele_type", TETRAHEDRA10)
+        self.load_increments_count = kw.get("load_increments_count", 1)
+        self.desired_tolerance = kw.get("desired_tolerance", 1e-8)
+        self.max_newton_count = kw.get("max_newton_count", 20)
+        self.modified_newton = kw.get("modified_newton", True)
+        self.gauss_nodes_count = kw.get("gauss_nodes_count", 5)
+        self.nodes = np.ascontiguousarray(kw["nodes"], dtype=np.float64)
+        self.elements = np.ascontiguousarray(kw["elements"], dtype=np.int32)
+        self.nodes_per_element = self.elements.shape[1]
+        self.presc_node = np.ascontiguousarray(kw.get("presc_node", []), dtype=np.int32)
+        self.presc_type = np.ascontiguousarray(kw.get("presc_type", []), dtype=np.int32)
+        self.presc_values = np.ascontiguousarray(kw.get("presc_values", np.zeros((0, 3))), dtype=np.float64).reshape(-1, 3)
+
+    @staticmethod
+    def load(path):
+        """Reads a .sexp deck through the product's C reader."""
+        h = load_host_library()
+        fd = FeaDeck()
+        err = C.create_string_buffer(512)
+        if h.fea_deck_load(os.fsencode(path), C.byref(fd), err, 512) != 0:
+            raise FeaHipError(f"{path}: {err.value.decode()}")
+        try:
+            n, e, npe, nb = fd.nodes_count, fd.elements_count, fd.nodes_per_element, fd.prescribed_nodes_count
+            deck = Deck(
+                model=fd.model, parameters=[fd.parameters[0], fd.parameters[1]], solver_type=fd.solver_type,
+                solver_tolerance=fd.solver_tolerance, solver_max_iter=fd.solver_max_iter, ele_type=fd.ele_type,
+                load_increments_count=fd.load_increments_count, desired_tolerance=fd.desired_tolerance,
+                max_newton_count=fd.max_newton_count, modified_newton=bool(fd.modified_newton),
+                gauss_nodes_count=fd.gauss_nodes_count,
+                nodes=np.ctypeslib.as_array(fd.nodes, (n, 3)).copy(),
+                elements=np.ctypeslib.as_array(fd.elements, (e, npe)).copy(),
+                presc_node=np.ctypeslib.as_array(fd.presc_node, (nb,)).copy() if nb else [],
+                presc_type=np.ctypeslib.as_array(fd.presc_type, (nb,)).copy() if nb else [],
+                presc_values=np.ctypeslib.as_array(fd.presc_values, (nb, 3)).copy() if nb else np.zeros((0, 3)))
+            deck.linesearch_max, deck.arclength_max = fd.linesearch_max, fd.arclength_max
+            return deck
+        finally:
+            h.fea_deck_free(C.byref(fd))
+
+    def to_struct(self):
+        fd = FeaDeck()
+        fd.model = self.model
+        fd.parameters[0], fd.parameters[1] = float(self.parameters[0]), float(self.parameters[1])
+        fd.parameters_count = 2
+        fd.solver_type, fd.solver_tolerance, fd.solver_max_iter = self.solver_type, self.solver_tolerance, self.solver_max_iter
+        fd.ele_type = self.ele_type
+        fd.load_increments_count, fd.desired_tolerance = self.load_increments_count, self.desired_tolerance
+        fd.max_newton_count, fd.modified_newton = self.max_newton_count, int(self.modified_newton)
+        fd.nodes_per_element, fd.gauss_nodes_count = self.nodes_per_element, self.gauss_nodes_count
+        fd.nodes_count, fd.nodes = len(self.nodes), _d(self.nodes)
+        fd.elements_count, fd.elements = len(self.elements), _i(self.elements)
+        fd.prescribed_nodes_count = len(self.presc_node)
+        fd.presc_node, fd.presc_type, fd.presc_values = _i(self.presc_node), _i(self.presc_type), _d(self.presc_values)
+        return fd
+
+    def save(self, path):
+        h = load_host_library()
+        fd = self.to_struct()
+        if h.fea_deck_save(os.fsencode(path), C.byref(fd)) != 0:
+            raise FeaHipError(f"could not write {path}")
+
+
+class FeaSolver:
+    """The `fea_solver` object of the reference, backed by the HIP context.
+
+    Method names are the reference's solver_* functions minus the prefix
+    (fea_solver.h:497-610)."""
+
+    def __init__(self, deck, device=0):
+        self._lib = load_library()
+        self._ctx = C.c_void_p()
+        self.deck = deck
+        w, _, dforms = element_tables(deck.ele_type, deck.gauss_nodes_count)
+        self.N, self.E = len(deck.nodes), len(deck.elements)
+        self.npe, self.G = deck.nodes_per_element, deck.gauss_nodes_count
+        self.ndof = 3 * self.N
+        par = np.zeros(10)
+        par[:2] = deck.parameters[:2]
+        rc = self._lib.feahip_create(
+            C.byref(self._ctx), device, self.N, self.E, self.npe, self.G, _d(w), _d(dforms), _i(deck.elements),
+            _d(deck.nodes), deck.model, _d(par), 2, len(deck.presc_node), _i(deck.presc_node), _i(deck.presc_type),
+            _d(deck.presc_values))
+        if rc != 0:
+            self._ctx = C.c_void_p()
+            raise FeaHipError(f"feahip_create failed ({rc}): {self._lib.feahip_create_error().decode()}")
+
+    def close(self):
+        if self._ctx:
+            self._lib.feahip_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise FeaHipError(f"libfeahip error {rc}: {self._lib.feahip_last_error(self._ctx).decode()}")
+
+    # ---- the calls of solve() ------------------------------------------
+    def update_nodes_with_bc(self, lam):
+        self._chk(self._lib.feahip_update_nodes_with_bc(self._ctx, lam))
+
+    def update_state(self):
+        bad = C.c_int(0)
+        self._chk(self._lib.feahip_update_state(self._ctx, C.byref(bad)))
+        return bad.value
+
+    def create_stiffness(self):
+        self._chk(self._lib.feahip_create_stiffness(self._ctx))
+
+    def create_residual_forces(self):
+        self._chk(self._lib.feahip_create_residual_forces(self._ctx))
+
+    def create_stiffness_and_residual(self):
+        self._chk(self._lib.feahip_create_stiffness_and_residual(self._ctx))
+
+    def stash_stiffness(self):
+        self._chk(self._lib.feahip_stash_stiffness(self._ctx))
+
+    def restore_stiffness(self):
+        self._chk(self._lib.feahip_restore_stiffness(self._ctx))
+
+    def apply_prescribed_bc(self, lam):
+        self._chk(self._lib.feahip_apply_prescribed_bc(self._ctx, lam))
+
+    def solve_slae(self, solver_type=None, tolerance=None, max_iterations=None):
+        it, res = C.c_int(0), C.c_double(0)
+        d = self.deck
+        self._chk(self._lib.feahip_solve_slae(
+            self._ctx, d.solver_type if solver_type is None else solver_type,
+            d.solver_tolerance if tolerance is None else tolerance,
+            d.solver_max_iter if max_iterations is None else max_iterations, C.byref(it), C.byref(res)))
+        return it.value, res.value
+
+    def energy(self):
+        t = C.c_double(0)
+        self._chk(self._lib.feahip_energy(self._ctx, C.byref(t)))
+        return t.value
+
+    def update_nodes_with_solution(self, u=None):
+        if u is None:
+            self._chk(self._lib.feahip_update_nodes_with_solution(self._ctx, None))
+        else:
+            u = np.ascontiguousarray(u, dtype=np.float64)
+            self._chk(self._lib.feahip_update_nodes_with_solution(self._ctx, _d(u)))
+
+    def solve(self, load_increments=None, max_newton=None, modified_newton=None, desired_tolerance=None,
+              solver_type=None, solver_tolerance=None, solver_max_iter=None):
+        d = self.deck
+        li = d.load_increments_count if load_increments is None else load_increments
+        mn = d.max_newton_count if max_newton is None else max_newton
+        cap = li * mn
+        tol_log = np.zeros(cap)
+        its = np.zeros(li, dtype=np.int32)
+        done = C.c_int(0)
+        self._chk(self._lib.feahip_solve(
+            self._ctx, li, mn, int(d.modified_newton if modified_newton is None else modified_newton),
+            d.desired_tolerance if desired_tolerance is None else desired_tolerance,
+            d.solver_type if solver_type is None else solver_type,
+            d.solver_tolerance if solver_tolerance is None else solver_tolerance,
+            d.solver_max_iter if solver_max_iter is None else solver_max_iter,
+            _d(tol_log), cap, _i(its), C.byref(done)))
+        n = int(its[:max(done.value, 0) + (1 if done.value < li else 0)].sum())
+        return done.value, its, tol_log[:n]
+
+    # ---- views -----------------------------------------------------------
+    def set_nodes(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.shape == (self.N, 3)
+        self._chk(self._lib.feahip_set_nodes(self._ctx, _d(x)))
+
+    def nodes(self):
+        x = np.zeros((self.N, 3))
+        self._chk(self._lib.feahip_get_nodes(self._ctx, _d(x)))
+        return x
+
+    def forces(self):
+        f = np.zeros(self.ndof)
+        self._chk(self._lib.feahip_get_forces(self._ctx, _d(f)))
+        return f
+
+    def set_forces(self, f):
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        assert f.shape == (self.ndof,)
+        self._chk(self._lib.feahip_set_forces(self._ctx, _d(f)))
+
+    def solution(self):
+        u = np.zeros(self.ndof)
+        self._chk(self._lib.feahip_get_solution(self._ctx, _d(u)))
+        return u
+
+    def graddefs(self):
+        F = np.zeros((self.E, self.G, 3, 3))
+        self._chk(self._lib.feahip_get_graddefs(self._ctx, _d(F)))
+        return F
+
+    def stresses(self):
+        S = np.zeros((self.E, self.G, 3, 3))
+        self._chk(self._lib.feahip_get_stresses(self._ctx, _d(S)))
+        return S
+
+    def matrix_yale(self):
+        nnz = C.c_longlong(0)
+        self._chk(self._lib.feahip_matrix_nnz(self._ctx, C.byref(nnz)))
+        off = np.zeros(self.ndof + 1, dtype=np.int32)
+        idx = np.zeros(nnz.value, dtype=np.int32)
+        val = np.zeros(nnz.value)
+        self._chk(self._lib.feahip_get_matrix_yale(self._ctx, _i(off), _i(idx), _d(val)))
+        return off, idx, val
+
+    def spmv(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros(self.ndof)
+        self._chk(self._lib.feahip_spmv(self._ctx, _d(x), _d(y)))
+        return y
+
+    # ---- tuning / measurement ------------------------------------------
+    def set_assembly(self, strategy):
+        self._chk(self._lib.feahip_set_assembly(self._ctx, strategy))
+
+    def sync(self):
+        self._chk(self._lib.feahip_sync(self._ctx))
+
+    def time_kernel(self, what, warmup=2, iters=10):
+        ms = C.c_double(0)
+        self._chk(self._lib.feahip_time_kernel(self._ctx, what, warmup, iters, C.byref(ms)))
+        return ms.value
+
+    def sizes(self):
+        o = (C.c_longlong * 8)()
+        self._chk(self._lib.feahip_sizes(self._ctx, o))
+        keys = ["N", "E", "npe", "G", "nnzb", "nchunks", "aux_bytes", "max_rowlen"]
+        return dict(zip(keys, [int(v) for v in o]))

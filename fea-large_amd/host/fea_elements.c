@@ -1,0 +1,103 @@
+/*
+ * fea_elements.c -- host-side element plug-in: Gauss rules and shape-function
+ * tables handed to the device through feahip_create().
+ *
+ * The reference binds isoform_t / disoform_t function pointers and a Gauss
+ * table per element type (fea_solver.c:1491-1506) and tabulates them per
+ * Gauss point in solver_gauss_node_alloc (:503-535).  Device code cannot
+ * call host pointers, so the tabulation is the interface: weights[G],
+ * forms[G][npe], dforms[G][3][npe].
+ *
+ * TETRAHEDRA10 with 4 or 5 points is the reference's element; its 4-point
+ * rule uses the 8-digit literals of fea_solver.c:33-47 on purpose.
+ * TETRAHEDRA4 (1 point) is a build extension for the BASELINE.json
+ * linear-tet configurations: corner shape functions, centroid rule.
+ */
+#include <string.h>
+#include "fea_host.h"
+
+/* local node order: corners 0-3, mid-sides 4:(0,1) 5:(1,2) 6:(0,2) 7:(0,3)
+ * 8:(1,3) 9:(2,3) -- fea_solver.c:1287-1304 */
+static double t10_N(int i, double r, double s, double t)
+{
+  const double u = 1 - r - s - t;
+  switch (i) {
+  case 0: return (2 * u - 1) * u;
+  case 1: return (2 * r - 1) * r;
+  case 2: return (2 * s - 1) * s;
+  case 3: return (2 * t - 1) * t;
+  case 4: return 4 * r * u;
+  case 5: return 4 * r * s;
+  case 6: return 4 * s * u;
+  case 7: return 4 * t * u;
+  case 8: return 4 * r * t;
+  default: return 4 * s * t;
+  }
+}
+
+/* d N_i / d(r,s,t)[d] -- fea_solver.c:1306-1373 */
+static double t10_dN(int i, int d, double r, double s, double t)
+{
+  const double c0 = 4 * t + 4 * s + 4 * r - 3;
+  static const int corner_axis[4] = {-1, 0, 1, 2};
+  double v[3] = {r, s, t};
+  if (i == 0) return c0;
+  if (i < 4) return corner_axis[i] == d ? 4 * v[d] - 1 : 0;
+  switch (i) {
+  case 4: return d == 0 ? -4 * t - 4 * s - 8 * r + 4 : -4 * r;
+  case 5: return d == 0 ? 4 * s : (d == 1 ? 4 * r : 0);
+  case 6: return d == 1 ? -4 * t - 8 * s - 4 * r + 4 : -4 * s;
+  case 7: return d == 2 ? -8 * t - 4 * s - 4 * r + 4 : -4 * t;
+  case 8: return d == 0 ? 4 * t : (d == 2 ? 4 * r : 0);
+  default: return d == 1 ? 4 * t : (d == 2 ? 4 * s : 0);
+  }
+}
+
+static double t4_N(int i, double r, double s, double t)
+{
+  switch (i) {
+  case 0: return 1 - r - s - t;
+  case 1: return r;
+  case 2: return s;
+  default: return t;
+  }
+}
+
+static double t4_dN(int i, int d) { return i == 0 ? -1 : (i - 1 == d ? 1 : 0); }
+
+int fea_element_tables(int ele_type, int G, double *weights, double *forms, double *dforms)
+{
+  /* {weight (divisor 6 inside), r, s, t} */
+  static const double a = 0.58541020, b = 0.13819660;
+  double rule[5][4];
+  int npe, g, i, d;
+  if (ele_type == FEA_TETRAHEDRA10) npe = 10;
+  else if (ele_type == FEA_TETRAHEDRA4) npe = 4;
+  else return -1;
+  memset(rule, 0, sizeof rule);
+  if (G == 4) {
+    for (g = 0; g < 4; ++g) {
+      rule[g][0] = (1 / 4.) / 6.;
+      rule[g][1] = g == 0 ? a : b; rule[g][2] = g == 1 ? a : b; rule[g][3] = g == 2 ? a : b;
+    }
+  } else if (G == 5) {
+    rule[0][0] = (-4 / 5.) / 6.; rule[0][1] = rule[0][2] = rule[0][3] = 1 / 4.;
+    for (g = 1; g < 5; ++g) {
+      rule[g][0] = (9 / 20.) / 6.;
+      rule[g][1] = g == 1 ? 1 / 2. : 1 / 6.; rule[g][2] = g == 2 ? 1 / 2. : 1 / 6.; rule[g][3] = g == 3 ? 1 / 2. : 1 / 6.;
+    }
+  } else if (G == 1 && ele_type == FEA_TETRAHEDRA4) {
+    rule[0][0] = 1 / 6.; rule[0][1] = rule[0][2] = rule[0][3] = 1 / 4.;
+  } else
+    return -1;                      /* fea_solver.c:1495-1504 rejects others */
+  for (g = 0; g < G; ++g) {
+    const double r = rule[g][1], s = rule[g][2], t = rule[g][3];
+    weights[g] = rule[g][0];
+    for (i = 0; i < npe; ++i) {
+      if (forms) forms[g * npe + i] = npe == 10 ? t10_N(i, r, s, t) : t4_N(i, r, s, t);
+      for (d = 0; d < 3; ++d)
+        dforms[(g * 3 + d) * npe + i] = npe == 10 ? t10_dN(i, d, r, s, t) : t4_dN(i, d);
+    }
+  }
+  return npe;
+}

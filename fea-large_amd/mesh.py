@@ -1,0 +1,150 @@
+"""Synthetic decks: Kuhn-tetrahedralised blocks on the reference's bar.
+
+The reference ships five TET10 decks of a 1 x 6 x 1 bar [0,1]x[1,7]x[0,1]
+(solver-large/data/*.sexp) generated from TetGen output by
+utilities/tetgenProcessor/FEATask.hs:177-207.  BASELINE.json asks for 1M-50M
+element blocks, which do not exist in the reference, so they are generated
+here on the same bar with the same boundary-condition recipe (end faces
+y = 1 and y = 7 prescribed, 0.05-style increments along y).
+
+Block of nx x ny x nz cubes, 6 tetrahedra per cube sharing the (0,0,0)-(1,1,1)
+diagonal (one per axis permutation); odd permutations get vertices 1 and 2
+swapped so every signed volume is positive.  Node numbering: x fastest, then
+z, y slowest -- so a contiguous range of node ids is a slab across the long
+axis (what the multi-GPU row partition cuts).  TET10 mid-side nodes sit on the
+exact edge mid-points, which are precisely the remaining points of the
+half-spacing grid; local order 4:(0,1) 5:(1,2) 6:(0,2) 7:(0,3) 8:(1,3) 9:(2,3)
+as fea_solver.c:1287-1300.
+"""
+import itertools
+import math
+
+import numpy as np
+
+from feahip import (CG, MODEL_COMPRESSIBLE_NEOHOOKEAN, TETRAHEDRA4, TETRAHEDRA10, Deck)
+
+_EDGES = [(0, 1), (1, 2), (0, 2), (0, 3), (1, 3), (2, 3)]
+
+
+def _kuhn_corner_offsets():
+    tets = []
+    for perm in itertools.permutations(range(3)):
+        v = [np.zeros(3, dtype=np.int64)]
+        for ax in perm:
+            nxt = v[-1].copy()
+            nxt[ax] += 1
+            v.append(nxt)
+        inv = sum(1 for i in range(3) for j in range(i + 1, 3) if perm[i] > perm[j])
+        if inv % 2 == 1:
+            v[1], v[2] = v[2], v[1]
+        tets.append(np.stack(v))
+    return np.stack(tets)            # [6][4][3]
+
+
+def block_dims(n):
+    """The BASELINE block of isotropic cubes n x 6n x n."""
+    return n, 6 * n, n
+
+
+def kuhn_block(nx, ny, nz, quadratic=False, origin=(0.0, 1.0, 0.0), size=(1.0, 6.0, 1.0)):
+    """(nodes[N][3], elements[E][4 or 10]) of the block."""
+    off = _kuhn_corner_offsets()
+    m = 2 if quadratic else 1          # grid refinement: TET10 nodes live on the half-spacing grid
+    gx, gy, gz = m * nx + 1, m * ny + 1, m * nz + 1
+
+    def nid(i, j, k):                  # x fastest, then z, y slowest
+        return (j * gz + k) * gx + i
+
+    ci, cj, ck = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    # cube order follows the node order (y slowest) so elements are sorted like their nodes
+    order = np.lexsort((ci.ravel(), ck.ravel(), cj.ravel()))
+    cubes = np.stack([ci.ravel()[order], cj.ravel()[order], ck.ravel()[order]], axis=1)   # [C][3]
+    corner = cubes[:, None, None, :] + off[None, :, :, :]            # [C][6][4][3] in cube units
+    corner = corner.reshape(-1, 4, 3) * m                             # grid units
+    cols = [nid(corner[:, a, 0], corner[:, a, 1], corner[:, a, 2]) for a in range(4)]
+    if quadratic:
+        for (a, b) in _EDGES:
+            mid = (corner[:, a, :] + corner[:, b, :]) // 2
+            cols.append(nid(mid[:, 0], mid[:, 1], mid[:, 2]))
+    elements = np.stack(cols, axis=1).astype(np.int32)
+
+    j, k, i = np.meshgrid(np.arange(gy), np.arange(gz), np.arange(gx), indexing="ij")
+    nodes = np.empty((gx * gy * gz, 3))
+    nodes[:, 0] = origin[0] + size[0] * i.ravel() / (gx - 1)
+    nodes[:, 1] = origin[1] + size[1] * j.ravel() / (gy - 1)
+    nodes[:, 2] = origin[2] + size[2] * k.ravel() / (gz - 1)
+    return nodes, elements
+
+
+def bar_boundary(nodes, recipe, dy):
+    """Prescribed displacements on the end faces y=min and y=max.
+
+    "clamped":  every end-face node type 7 (as data/neohook_brick.sexp).
+    "uniaxial": end faces type 2 (y only, as data/*_analytical.sexp), corner
+                A=(xmin,ymin,zmin) type 7 and corner B=(xmax,ymin,zmin) type 6;
+                the extra z pin at B removes the rigid rotation about y that
+                the reference's analytical decks leave free."""
+    y = nodes[:, 1]
+    lo, hi = y.min(), y.max()
+    eps = 1e-9 * (hi - lo)
+    bot = np.nonzero(np.abs(y - lo) < eps)[0]
+    top = np.nonzero(np.abs(y - hi) < eps)[0]
+    ids = np.concatenate([bot, top]).astype(np.int32)
+    vals = np.zeros((len(ids), 3))
+    vals[len(bot):, 1] = dy
+    if recipe == "clamped":
+        types = np.full(len(ids), 7, dtype=np.int32)
+    elif recipe == "uniaxial":
+        types = np.full(len(ids), 2, dtype=np.int32)
+        xb, zb = nodes[bot, 0], nodes[bot, 2]
+        a = np.argmin(xb + zb)                              # (xmin, zmin)
+        b = np.argmin(-xb + zb + 2 * (xb.max() - xb.min()))  # (xmax, zmin)
+        types[a] = 7
+        types[b] = 6
+    else:
+        raise ValueError(recipe)
+    return ids, types, vals
+
+
+def increment_for(n):
+    """Per-increment face displacement: the decks' 0.05, kept below the
+    element size so the bumped face layer is not inverted."""
+    return 0.05 * min(1.0, 4.0 / n)
+
+
+def bar_deck(n=None, dims=None, quadratic=False, recipe="clamped", model=MODEL_COMPRESSIBLE_NEOHOOKEAN,
+             gauss=None, dy=None, **kw):
+    nx, ny, nz = dims if dims is not None else block_dims(n)
+    nodes, elements = kuhn_block(nx, ny, nz, quadratic)
+    if dy is None:
+        dy = increment_for(max(nx, nz))
+    ids, types, vals = bar_boundary(nodes, recipe, dy)
+    if gauss is None:
+        gauss = 5 if quadratic else 1
+    kw.setdefault("solver_type", CG)
+    return Deck(model=model, parameters=[100.0, 100.0], ele_type=TETRAHEDRA10 if quadratic else TETRAHEDRA4,
+                gauss_nodes_count=gauss, nodes=nodes, elements=elements, presc_node=ids, presc_type=types,
+                presc_values=vals, **kw)
+
+
+def neohookean_lateral_stretch(k1, lam=100.0, mu=100.0):
+    """k2 of the uniaxial state: root of mu(k2^2-1)+lam ln(k1 k2^2) = 0
+    (exact-solutions/uniaxial/uniaxial_neohookean_bonet.m:20-26)."""
+    k2 = 1.0
+    for _ in range(60):
+        f = mu * (k2 * k2 - 1) + lam * math.log(k1 * k2 * k2)
+        df = 2 * mu * k2 + 2 * lam / k2
+        k2 -= f / df
+    return k2
+
+
+def deformed_state(nodes, k1=1.1, wiggle=1e-3):
+    """Current coordinates for assembly-only runs: the homogeneous uniaxial
+    state at stretch k1 plus a smooth deterministic perturbation so F differs
+    per element."""
+    k2 = neohookean_lateral_stretch(k1)
+    A = nodes.min(axis=0)
+    x = A + (nodes - A) * np.array([k2, k1, k2])
+    X = nodes
+    u = wiggle * np.sin(2 * np.pi * X[:, 0]) * np.sin(np.pi * (X[:, 1] - 1.0) / 3.0) * np.sin(2 * np.pi * X[:, 2])
+    return x + u[:, None]

@@ -1,0 +1,168 @@
+/*
+ * fea_hip.h -- C ABI of the MI355X-native assembly + Newton hot path.
+ *
+ * One opaque context replaces the `fea_solver` object of the reference for
+ * the calls that `solve()` makes inside its load-increment / Newton loops
+ * (solver-large/fea_solver.c:130-242).  Every entry below names the
+ * reference function it stands in for.  Plain pointers and sizes only; all
+ * host arrays are copied (caller keeps ownership); getters fill caller-owned
+ * host buffers in the reference's own shapes.
+ *
+ * Every function returns 0 on success or a negative FEAHIP_E* code, never
+ * exits and never asserts (the reference's error() calls exit(),
+ * fea_solver.c:57-61).  feahip_last_error() gives the message.
+ * A context is single-caller (the reference is single-threaded).
+ */
+#ifndef FEA_HIP_H
+#define FEA_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct feahip_ctx feahip_ctx;
+
+enum {
+  FEAHIP_OK = 0,
+  FEAHIP_EINVAL = -1,      /* bad argument / unsupported combination        */
+  FEAHIP_ENODEVICE = -2,   /* no usable HIP device: the path has no CPU mode */
+  FEAHIP_EHIP = -3,        /* a HIP runtime call failed                      */
+  FEAHIP_ENOMEM = -4,
+  FEAHIP_ESTATE = -5,      /* call order violated (e.g. restore before stash)*/
+  FEAHIP_ENOTCONVERGED = -6,
+  FEAHIP_ECOMM = -7        /* RCCL failure                                   */
+};
+
+/* material models, numbered as `model_type` (fea_model.h:37-40) */
+enum { FEAHIP_MODEL_A5 = 0, FEAHIP_MODEL_COMPRESSIBLE_NEOHOOKEAN = 1 };
+/* linear solvers, numbered as `slae_solver_type` (fea_solver.h:62-66).
+ * CG = conjugate gradients started from x0 = rhs (fea_solver.c:251-256);
+ * PCG_ILU and CHOLESKY have no GPU-idiomatic twin: both run diagonally
+ * (3x3 block) preconditioned CG, CHOLESKY iterated to stagnation.           */
+enum { FEAHIP_CG = 0, FEAHIP_PCG_ILU = 1, FEAHIP_CHOLESKY = 2 };
+/* assembly strategies */
+enum {
+  FEAHIP_ASM_AUTO = 0,
+  FEAHIP_ASM_ROWOWNER = 1, /* node-centric gather, every CSR value written
+                              once, deterministic                            */
+  FEAHIP_ASM_ATOMIC = 2    /* element-parallel, FP64 atomics into the CSR    */
+};
+
+/* ---- lifetime ----------------------------------------------------------- */
+
+/* Stands in for fea_solver_alloc (fea_solver.c:387-456) plus
+ * solver_create_element_database (:556-571): the element plug-in arrives as
+ * the tables solver_gauss_node_alloc tabulates (:503-535) -- weights[G]
+ * (divisor 6 already inside) and dforms[G][3][npe] -- because device code
+ * cannot call the host's isoform_t/disoform_t pointers (fea_solver.h:34-40).
+ * The material plug-in arrives as (model, parameters[]) of `fea_model`
+ * (fea_model.h:46-57): parameters[0] = lambda, parameters[1] = mu.
+ * elements: [n_elems][npe] 0-based node ids (elements_array, :132-138)
+ * nodes0:   [n_nodes][3]   initial coordinates (nodes_array, :124-128)
+ * presc_*:  prescribed_bnd_node fields (:142-146), deck order.              */
+int feahip_create(feahip_ctx **out, int device,
+                  int n_nodes, int n_elems, int npe, int gauss_count,
+                  const double *gauss_weights, const double *dforms,
+                  const int *elements, const double *nodes0,
+                  int model, const double *model_params, int params_count,
+                  int n_presc, const int *presc_node, const int *presc_type,
+                  const double *presc_values);
+
+/* fea_solver_free (fea_solver.c:459-501); frees device memory only. */
+void feahip_destroy(feahip_ctx *ctx);
+
+const char *feahip_last_error(const feahip_ctx *ctx);
+/* message of the last failed feahip_create (no context exists then) */
+const char *feahip_create_error(void);
+
+/* ---- the calls of solve() ---------------------------------------------- */
+
+/* solver_update_nodes_with_bc (fea_solver.c:1281-1284): x[c] += lambda*value
+ * for every prescribed dof.                                                 */
+int feahip_update_nodes_with_bc(feahip_ctx *ctx, double lambda);
+
+/* solver_create_current_shape_gradients + solver_create_stresses
+ * (fea_solver.c:831-861).  The assembly kernels recompute J, grad N, F and
+ * sigma in registers, so this only invalidates the cached per-Gauss-point
+ * F / sigma that feahip_get_graddefs / feahip_get_stresses serve; it also
+ * returns, in *n_bad (may be NULL), the count of Gauss points whose current
+ * Jacobian determinant is <= 0 as seen by the last assembly.               */
+int feahip_update_state(feahip_ctx *ctx, int *n_bad);
+
+/* solver_create_stiffness (fea_solver.c:873-883): K = sum_e (Kc + Ksigma). */
+int feahip_create_stiffness(feahip_ctx *ctx);
+/* solver_create_residual_forces (fea_solver.c:863-870): f = -T.            */
+int feahip_create_residual_forces(feahip_ctx *ctx);
+/* both in one pass over the mesh (what a full-Newton iteration needs)      */
+int feahip_create_stiffness_and_residual(feahip_ctx *ctx);
+
+/* sp_matrix_copy(global -> stiffness) (fea_solver.c:179) and
+ * sp_matrix_free + sp_matrix_copy(stiffness -> global) (:194-195).         */
+int feahip_stash_stiffness(feahip_ctx *ctx);
+int feahip_restore_stiffness(feahip_ctx *ctx);
+
+/* solver_apply_prescribed_bc (fea_solver.c:1200-1257): for every prescribed
+ * dof c with p = lambda*value: f[r] -= K[r,c]*p, row and column c zeroed
+ * keeping K[c,c], f[c] = K[c,c]*p.                                          */
+int feahip_apply_prescribed_bc(feahip_ctx *ctx, double lambda);
+
+/* solver_solve_slae (fea_solver.c:300-321): solve K u = f.  iters / resid
+ * (relative residual ||f-Ku||/||f||) may be NULL.                          */
+int feahip_solve_slae(feahip_ctx *ctx, int solver_type, double tolerance,
+                      int max_iterations, int *iters, double *resid);
+
+/* cdot(global_forces_vct, global_solution_vct) (fea_solver.c:208-210).     */
+int feahip_energy(feahip_ctx *ctx, double *tolerance);
+
+/* solver_update_nodes_with_solution (fea_solver.c:1270-1279): x += u.
+ * u == NULL uses the device-resident solution of the last solve.           */
+int feahip_update_nodes_with_solution(feahip_ctx *ctx, const double *u);
+
+/* The whole loop of solve() (fea_solver.c:163-236) run by the library.
+ * tol_log[tol_log_cap] receives <u,f> of every Newton iteration, its_log
+ * [load_increments] the iteration count of every step (either may be NULL).
+ * *steps_done = number of completed load steps.                             */
+int feahip_solve(feahip_ctx *ctx, int load_increments, int max_newton,
+                 int modified_newton, double desired_tolerance,
+                 int solver_type, double solver_tolerance, int solver_max_iter,
+                 double *tol_log, int tol_log_cap, int *its_log,
+                 int *steps_done);
+
+/* ---- reference-shaped views -------------------------------------------- */
+
+int feahip_set_nodes(feahip_ctx *ctx, const double *nodes);   /* nodes_p    */
+int feahip_get_nodes(feahip_ctx *ctx, double *nodes);         /* [N][3]     */
+int feahip_get_forces(feahip_ctx *ctx, double *f);            /* [3N]       */
+int feahip_set_forces(feahip_ctx *ctx, const double *f);
+int feahip_get_solution(feahip_ctx *ctx, double *u);          /* [3N]       */
+/* graddefs[e][g].components / stresses[e][g].components
+ * (fea_solver.h:262-269), layout [E][G][3][3]                               */
+int feahip_get_graddefs(feahip_ctx *ctx, double *F);
+int feahip_get_stresses(feahip_ctx *ctx, double *S);
+
+/* global_mtx in sp_matrix_yale shape (fea_solver.c:303-304): scalar CSR of
+ * the full symmetric pattern, sorted columns.                               */
+int feahip_matrix_nnz(feahip_ctx *ctx, long long *nnz);
+int feahip_get_matrix_yale(feahip_ctx *ctx, int *offsets, int *indexes,
+                           double *values);
+/* y = K x with host vectors (test hook for the SpMV kernel)                 */
+int feahip_spmv(feahip_ctx *ctx, const double *x, double *y);
+
+/* ---- tuning and measurement -------------------------------------------- */
+
+int feahip_set_assembly(feahip_ctx *ctx, int strategy);
+int feahip_sync(feahip_ctx *ctx);
+/* Runs `iters` timed launches of one hot-path kernel after `warmup` untimed
+ * ones, bracketed by HIP events on the context's own stream; *avg_ms is the
+ * mean device time of one launch.  what: 0 stiffness+residual assembly,
+ * 1 stiffness only, 2 residual only, 3 SpMV, 4 one PCG iteration.           */
+int feahip_time_kernel(feahip_ctx *ctx, int what, int warmup, int iters,
+                       double *avg_ms);
+/* sizes the roofline model needs: N, E, npe, G, block rows, blocks, and the
+ * bytes of the auxiliary maps the kernels read                              */
+int feahip_sizes(feahip_ctx *ctx, long long *out8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
