@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- element-stiffness assemblies/s on the BASELINE.json block.
+
+A step = one pass of the hot path over the mesh: stiffness + residual
+assembly of every element (state evaluation at the Gauss points included,
+one-time pattern build excluded), inputs resident in HBM.  Default workload:
+BASELINE.json configs[2], the 10M linear-tet Neo-Hookean block
+(66 x 396 x 66 Kuhn cubes on the reference's 1 x 6 x 1 bar).
+
+  python bench.py --gpus N --steps K --warmup W          (N = 1)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+With N > 1 the block rows (hence the elements that touch them) are sharded
+over the ranks as slabs across the long axis; assembly needs no collective,
+so the data path has none -- torch.distributed (RCCL) only carries the
+barrier and the max-over-ranks of the wall time.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "fea-large_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(npe, E, N, nnz):
+    """every input read once, every output written once --
+    int32 connectivity, X0 and x, FP64 CSR values, residual."""
+    return 4 * npe * E + 48 * N + 8 * nnz + 24 * N
+
+
+def spmv_bytes(nnz, N):
+    return 8 * nnz + 4 * nnz // 9 + 4 * (N + 1) + 48 * N
+
+
+def cpu_baseline(n_sample, seconds_cap=40.0):
+    """The oracle (CPU restatement of the reference loops, 1 thread) timed on
+    a bounded sample of the same workload: a smaller Kuhn block of the same
+    bar in the same deformed state."""
+    import mesh
+    from oracle_binding import OracleSolver
+    deck = mesh.bar_deck(n=n_sample)
+    o = OracleSolver(deck)
+    o.set_nodes(mesh.deformed_state(deck.nodes))
+    t0 = time.perf_counter()
+    o.update_state()
+    o.create_stiffness()
+    o.create_residual_forces()
+    dt = time.perf_counter() - t0
+    E = len(deck.elements)
+    return {"value": E / dt, "unit": "elements/s", "cores": 1, "kind": "port",
+            "sample": f"{E} TET4 of the same bar ({n_sample}x{6 * n_sample}x{n_sample} cubes), "
+                      f"state+stiffness+residual, {dt:.1f} s, oracle/fea_oracle.c -O2 -ffp-contract=off"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=66, help="block of n x 6n x n cubes (66 = 10M tets, 31 = 1M)")
+    ap.add_argument("--quadratic", action="store_true", help="TET10 / 5 Gauss points instead of TET4 / 1")
+    ap.add_argument("--model", default="neohookean", choices=["neohookean", "a5"])
+    ap.add_argument("--cpu-sample", type=int, default=20, help="n of the CPU-baseline sample block (0 = skip)")
+    ap.add_argument("--no-newton", action="store_true", help="skip the single full Newton iteration")
+    args = ap.parse_args()
+
+    import torch
+    import feahip
+    import mesh
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs an MI355X: the hot path has no CPU mode", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    model = feahip.MODEL_COMPRESSIBLE_NEOHOOKEAN if args.model == "neohookean" else feahip.MODEL_A5
+    t_setup = time.perf_counter()
+    deck = mesh.bar_deck(n=args.n, quadratic=args.quadratic, recipe="clamped", model=model,
+                         solver_type=feahip.PCG_ILU, solver_tolerance=1e-14, solver_max_iter=20000)
+    solver = feahip.FeaSolver(deck, device=local)
+    if world > 1:
+        solver.set_row_shard(rank, world)
+    solver.set_nodes(mesh.deformed_state(deck.nodes))
+    sz = solver.sizes()
+    t_setup = time.perf_counter() - t_setup
+
+    E_total, N, nnz = sz["E"], sz["N"], sz["nnzb"] * 9
+    for _ in range(args.warmup):
+        solver.create_stiffness_and_residual()
+    solver.sync(); torch.cuda.synchronize(); barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.create_stiffness_and_residual()
+    solver.sync(); torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = 1e3 * dt / args.steps
+    value = E_total * args.steps / dt
+
+    out = None
+    if rank == 0:
+        # dominant kernel, HIP events on the library's own stream
+        k_ms = solver.time_kernel(0, warmup=2, iters=max(5, args.steps))
+        share = 1.0 / world
+        B = algorithmic_bytes(sz["npe"], E_total, N, nnz) * share
+        achieved = B / (k_ms * 1e-3) / 1e9
+        spmv_ms = solver.time_kernel(3, warmup=2, iters=10)
+        pcg_ms = solver.time_kernel(4, warmup=2, iters=10)
+        extras = {
+            "assembly_kernel_ms": k_ms,
+            "residual_only_ms": solver.time_kernel(2, warmup=2, iters=10),
+            "spmv_ms": spmv_ms,
+            "spmv_GBps": spmv_bytes(nnz, N) * share / (spmv_ms * 1e-3) / 1e9,
+            "pcg_iteration_ms": pcg_ms,
+            "setup_s": t_setup,
+            "aux_map_bytes_per_element": sz["aux_bytes"] / E_total,
+        }
+        if not args.no_newton and world == 1:
+            # one full Newton iteration of the first load increment: bump, assemble, BC, PCG to 1e-14, update
+            solver.set_nodes(deck.nodes)
+            solver.sync()
+            tn = time.perf_counter()
+            solver.update_nodes_with_bc(1.0)
+            solver.create_stiffness_and_residual()
+            solver.apply_prescribed_bc(0.0)
+            its, res = solver.solve_slae(feahip.PCG_ILU, 1e-14, 20000)
+            en = solver.energy()
+            solver.update_nodes_with_solution()
+            solver.sync()
+            tn = time.perf_counter() - tn
+            extras.update({"newton_iters_per_s": 1.0 / tn, "newton_iteration_s": tn, "cg_iterations": its,
+                           "cg_relative_residual": res, "energy_u_f": en})
+        out = {
+            "metric": "element-stiffness assemblies/sec", "value": value, "unit": "elements/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{E_total} {'TET10/5GP' if args.quadratic else 'TET4/1GP'} {args.model} block "
+                                   f"({args.n}x{6 * args.n}x{args.n} Kuhn cubes on the 1x6x1 bar), "
+                                   f"stiffness+residual assembly, deformed state k1=1.1",
+                       "elements": E_total, "nodes": N, "scalar_nnz": nnz,
+                       "sharding": f"block rows in {world} slab(s) across y"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_assemble_rowowner", "algorithmic_bytes_per_launch": B},
+            "extras": extras,
+        }
+        if args.cpu_sample > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+    solver.close()
+    barrier()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

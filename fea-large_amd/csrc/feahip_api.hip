@@ -73,6 +73,7 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
   c->nnzb = (int)hp.colidx.size();
   c->max_rowlen = hp.max_rowlen;
   c->nchunks = (int)hp.chunk.size() - 1;
+  c->chunk0 = 0; c->nchunks_local = c->nchunks;
   c->h_rowptr = hp.rowptr; c->h_colidx = hp.colidx;
 
   if ((rc = dev_upload(c, &c->d_conn, elements, (size_t)n_elems * npe))) return rc;
@@ -181,6 +182,16 @@ extern "C" int feahip_set_assembly(feahip_ctx *c, int strategy)
   CTX_GUARD(c);
   if (strategy < FEAHIP_ASM_AUTO || strategy > FEAHIP_ASM_ATOMIC) { c->err = "unknown assembly strategy"; return FEAHIP_EINVAL; }
   c->strategy = strategy;
+  return FEAHIP_OK;
+}
+
+extern "C" int feahip_set_row_shard(feahip_ctx *c, int rank, int nranks)
+{
+  CTX_GUARD(c);
+  if (nranks < 1 || rank < 0 || rank >= nranks) { c->err = "bad shard (rank, nranks)"; return FEAHIP_EINVAL; }
+  // equal numbers of chunks = near-equal numbers of 3x3 blocks per rank
+  c->chunk0 = (int)((long long)c->nchunks * rank / nranks);
+  c->nchunks_local = (int)((long long)c->nchunks * (rank + 1) / nranks) - c->chunk0;
   return FEAHIP_OK;
 }
 

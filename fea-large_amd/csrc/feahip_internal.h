@@ -34,6 +34,7 @@ struct feahip_ctx {
   int N = 0, E = 0, npe = 0, G = 0, ndof = 0;
   int nnzb = 0;               // 3x3 blocks in the full symmetric pattern
   int nchunks = 0;
+  int chunk0 = 0, nchunks_local = 0;  // this rank's share of the chunks (row shard)
   int max_rowlen = 0;
   bool linear_tet = false;    // npe == 4 and dN is the constant-strain table
   int model = 0;

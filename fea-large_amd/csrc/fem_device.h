@@ -20,7 +20,7 @@
 #include "feahip_internal.h"
 
 struct AsmArgs {
-  int N, E, G, nchunks, model;
+  int N, E, G, nchunks, chunk0, model;   // chunks [chunk0, chunk0+nchunks) are this launch's
   double lambda, mu;
   const ElemTable *tab;
   const int *conn;

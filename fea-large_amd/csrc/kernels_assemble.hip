@@ -33,8 +33,8 @@ void k_assemble_rowowner(AsmArgs A)
   __shared__ double sK[FEA_WAVES_PER_WG][DOK ? FEA_CHUNK_BLOCKS * 9 : 1];
   __shared__ double sF[FEA_WAVES_PER_WG][FEA_CHUNK_ROWS * 3];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int chunk = blockIdx.x * FEA_WAVES_PER_WG + wave;
-  if (chunk >= A.nchunks) return;     // whole wave leaves; no block barrier below
+  const int chunk = A.chunk0 + blockIdx.x * FEA_WAVES_PER_WG + wave;
+  if (chunk >= A.chunk0 + A.nchunks) return;     // whole wave leaves; no block barrier below
   double *tK = sK[wave], *tF = sF[wave];
 
   const int r0 = A.chunk[chunk], r1 = A.chunk[chunk + 1];
@@ -216,7 +216,7 @@ void k_state_export(AsmArgs A)
 static AsmArgs make_args(feahip_ctx *c)
 {
   AsmArgs A;
-  A.N = c->N; A.E = c->E; A.G = c->G; A.nchunks = c->nchunks; A.model = c->model;
+  A.N = c->N; A.E = c->E; A.G = c->G; A.nchunks = c->nchunks_local; A.chunk0 = c->chunk0; A.model = c->model;
   A.lambda = c->lambda; A.mu = c->mu;
   A.tab = c->d_table; A.conn = c->d_conn; A.X0 = c->d_X0; A.x = c->d_x;
   A.rowptr = c->d_rowptr; A.colidx = c->d_colidx; A.K = c->d_K; A.f = c->d_f;
@@ -229,7 +229,7 @@ static AsmArgs make_args(feahip_ctx *c)
 template <int NPE, bool LINTET>
 static void launch_rowowner_t(feahip_ctx *c, const AsmArgs &A, bool doK, bool doF)
 {
-  const int grid = (c->nchunks + FEA_WAVES_PER_WG - 1) / FEA_WAVES_PER_WG;
+  const int grid = (c->nchunks_local + FEA_WAVES_PER_WG - 1) / FEA_WAVES_PER_WG;
   const dim3 blk(64 * FEA_WAVES_PER_WG);
   if (doK && doF) hipLaunchKernelGGL((k_assemble_rowowner<NPE, LINTET, true, true>), dim3(grid), blk, 0, c->stream, A);
   else if (doK)   hipLaunchKernelGGL((k_assemble_rowowner<NPE, LINTET, true, false>), dim3(grid), blk, 0, c->stream, A);

@@ -163,7 +163,7 @@ int launch_update_nodes_solution(feahip_ctx *c, const double *d_uv)
 // order.  No atomics; HBM sees each matrix byte once.
 // ------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
-void k_spmv(int nchunks, const int *chunk, const int *rowptr, const int *colidx, const double *K,
+void k_spmv(int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx, const double *K,
             const double *x, double *y, const double *dotwith, double *part, const int *flag)
 {
   __shared__ double sV[FEA_WAVES_PER_WG][FEA_CHUNK_BLOCKS * 9];
@@ -173,7 +173,7 @@ void k_spmv(int nchunks, const int *chunk, const int *rowptr, const int *colidx,
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double *tV = sV[wave], *tP = sP[wave];
   double dsum = 0;
-  for (int ch = blockIdx.x * FEA_WAVES_PER_WG + wave; ch < nchunks; ch += gridDim.x * FEA_WAVES_PER_WG) {
+  for (int ch = chunk0 + blockIdx.x * FEA_WAVES_PER_WG + wave; ch < chunk0 + nchunks; ch += gridDim.x * FEA_WAVES_PER_WG) {
     const int r0 = chunk[ch], r1 = chunk[ch + 1];
     const int b0 = rowptr[r0], nb = rowptr[r1] - b0;
     const double *Kc = K + (size_t)b0 * 9;
@@ -206,7 +206,7 @@ void k_spmv(int nchunks, const int *chunk, const int *rowptr, const int *colidx,
 
 static int spmv_grid(const feahip_ctx *c)
 {
-  int g = (c->nchunks + FEA_WAVES_PER_WG - 1) / FEA_WAVES_PER_WG;
+  int g = (c->nchunks_local + FEA_WAVES_PER_WG - 1) / FEA_WAVES_PER_WG;
   return g < FEA_RED_BLOCKS ? (g > 0 ? g : 1) : FEA_RED_BLOCKS;
 }
 static int vec_grid(const feahip_ctx *c)
@@ -217,7 +217,7 @@ static int vec_grid(const feahip_ctx *c)
 
 int launch_spmv(feahip_ctx *c, const double *d_xv, double *d_yv)
 {
-  hipLaunchKernelGGL(k_spmv, dim3(spmv_grid(c)), dim3(256), 0, c->stream, c->nchunks, c->d_chunk,
+  hipLaunchKernelGGL(k_spmv, dim3(spmv_grid(c)), dim3(256), 0, c->stream, c->chunk0, c->nchunks_local, c->d_chunk,
                      c->d_rowptr, c->d_colidx, c->d_K, d_xv, d_yv, (const double *)nullptr,
                      (double *)nullptr, (const int *)nullptr);
   FEA_HIP_CHECK(c, hipGetLastError());
@@ -397,7 +397,7 @@ void k_cg_direction(int N, int it, int nparts, const double *r, const double *mi
 static void enqueue_cg_iteration(feahip_ctx *c, int it)
 {
   const int gs = spmv_grid(c), gv = vec_grid(c);
-  hipLaunchKernelGGL(k_spmv, dim3(gs), dim3(256), 0, c->stream, c->nchunks, c->d_chunk, c->d_rowptr,
+  hipLaunchKernelGGL(k_spmv, dim3(gs), dim3(256), 0, c->stream, c->chunk0, c->nchunks_local, c->d_chunk, c->d_rowptr,
                      c->d_colidx, c->d_K, c->d_p, c->d_q, c->d_p, c->d_part, c->d_flag);
   hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(256), 0, c->stream, c->N, it, gs, c->d_p, c->d_q,
                      c->d_minv, c->d_u, c->d_r, c->d_part, c->d_scal, c->d_flag);

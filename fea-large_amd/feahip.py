@@ -54,6 +54,7 @@ ABI = {
     "feahip_get_matrix_yale": [C.c_void_p, _ip, _ip, _dp],
     "feahip_spmv": [C.c_void_p, _dp, _dp],
     "feahip_set_assembly": [C.c_void_p, C.c_int],
+    "feahip_set_row_shard": [C.c_void_p, C.c_int, C.c_int],
     "feahip_sync": [C.c_void_p],
     "feahip_time_kernel": [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp],
     "feahip_sizes": [C.c_void_p, C.POINTER(C.c_longlong)],
@@ -373,6 +374,9 @@ class FeaSolver:
     # ---- tuning / measurement ------------------------------------------
     def set_assembly(self, strategy):
         self._chk(self._lib.feahip_set_assembly(self._ctx, strategy))
+
+    def set_row_shard(self, rank, nranks):
+        self._chk(self._lib.feahip_set_row_shard(self._ctx, rank, nranks))
 
     def sync(self):
         self._chk(self._lib.feahip_sync(self._ctx))

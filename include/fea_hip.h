@@ -151,6 +151,11 @@ int feahip_spmv(feahip_ctx *ctx, const double *x, double *y);
 /* ---- tuning and measurement -------------------------------------------- */
 
 int feahip_set_assembly(feahip_ctx *ctx, int strategy);
+/* Restricts assembly and SpMV to this rank's slab of block rows (rank of
+ * nranks, contiguous row ranges of near-equal block count).  Rows are owned
+ * by exactly one rank; a rank visits every element that touches its rows, so
+ * assembly needs no exchange between ranks.                                  */
+int feahip_set_row_shard(feahip_ctx *ctx, int rank, int nranks);
 int feahip_sync(feahip_ctx *ctx);
 /* Runs `iters` timed launches of one hot-path kernel after `warmup` untimed
  * ones, bracketed by HIP events on the context's own stream; *avg_ms is the

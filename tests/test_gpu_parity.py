@@ -1,0 +1,300 @@
+"""Parity of the HIP path with the oracle, through the C ABI, on an MI355X.
+
+Bars: integer / index work (pattern, connectivity-derived offsets) is
+bit-exact; floating-point results agree to the tolerance written at each
+assert -- K_e and f to 1e-12 of their scale (re-association and FMA
+contraction only), displacements to 1e-10 relative (BASELINE.json).
+"""
+import gzip
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+import feahip
+import mesh
+from oracle_binding import OracleSolver
+
+pytestmark = pytest.mark.gpu
+
+K_TOL = 1e-12     # relative to max|K| (resp. max|f|)
+U_TOL = 1e-10     # BASELINE.json: displacements within 1e-10 relative
+
+
+def rel(a, b):
+    s = np.abs(b).max()
+    return np.abs(a - b).max() / (s if s > 0 else 1.0)
+
+
+def make_pair(deck, x=None):
+    s, o = feahip.FeaSolver(deck), OracleSolver(deck)
+    if x is not None:
+        s.set_nodes(x)
+        o.set_nodes(x)
+    return s, o
+
+
+def check_assembly(s, o, strategies=(feahip.ASM_ROWOWNER, feahip.ASM_ATOMIC)):
+    o.update_state()
+    o.create_stiffness()
+    o.create_residual_forces()
+    for strat in strategies:
+        s.set_assembly(strat)
+        s.create_stiffness_and_residual()
+        off, idx, val = s.matrix_yale()
+        assert np.array_equal(off, o.offsets())       # bit-exact indexing
+        assert np.array_equal(idx, o.indexes())
+        assert rel(val, o.values()) < K_TOL, strat
+        assert rel(s.forces(), o.forces()) < K_TOL, strat
+        # the separate entry points give the same bits as the fused one
+        s.create_stiffness()
+        assert np.array_equal(s.matrix_yale()[2], val) or strat == feahip.ASM_ATOMIC
+        s.create_residual_forces()
+        assert rel(s.forces(), o.forces()) < K_TOL
+    s.set_assembly(feahip.ASM_AUTO)
+
+
+@pytest.mark.parametrize("model", [feahip.MODEL_COMPRESSIBLE_NEOHOOKEAN, feahip.MODEL_A5])
+@pytest.mark.parametrize("dims", [(1, 1, 1), (3, 5, 2)])
+def test_tet4_assembly(model, dims):
+    deck = mesh.bar_deck(dims=dims, model=model)
+    s, o = make_pair(deck, mesh.deformed_state(deck.nodes, k1=1.08, wiggle=5e-3))
+    check_assembly(s, o)
+    assert rel(s.graddefs(), o.graddefs()) < 1e-13
+    assert rel(s.stresses(), o.stresses()) < 1e-12
+    s.close()
+
+
+@pytest.mark.parametrize("name", ["neohook_brick", "a5_brick"])
+def test_tet10_reference_deck_assembly(decks_dir, name):
+    deck = feahip.Deck.load(os.path.join(decks_dir, name + ".sexp"))
+    s, o = make_pair(deck, mesh.deformed_state(deck.nodes, k1=1.05, wiggle=2e-3))
+    check_assembly(s, o)
+    assert rel(s.graddefs(), o.graddefs()) < 1e-12
+    assert rel(s.stresses(), o.stresses()) < 1e-11
+    s.close()
+
+
+def test_tet10_four_point_rule(decks_dir):
+    deck = feahip.Deck.load(os.path.join(decks_dir, "neohook_brick.sexp"))
+    deck.gauss_nodes_count = 4
+    s, o = make_pair(deck, mesh.deformed_state(deck.nodes, k1=1.03))
+    check_assembly(s, o, strategies=(feahip.ASM_ROWOWNER,))
+    s.close()
+
+
+def test_rowowner_is_deterministic():
+    deck = mesh.bar_deck(dims=(4, 8, 4))
+    s = feahip.FeaSolver(deck)
+    s.set_nodes(mesh.deformed_state(deck.nodes))
+    s.create_stiffness_and_residual()
+    v1, f1 = s.matrix_yale()[2], s.forces()
+    s.create_stiffness_and_residual()
+    v2, f2 = s.matrix_yale()[2], s.forces()
+    # LDS adds of one wave may commute between runs; everything else is fixed
+    assert rel(v1, v2) < 1e-15 and rel(f1, f2) < 1e-15
+    s.close()
+
+
+def test_undeformed_state_is_stress_free_and_bump_moves_face():
+    deck = mesh.bar_deck(dims=(2, 6, 2), dy=0.05)
+    s, o = make_pair(deck)
+    s.create_residual_forces()
+    assert np.abs(s.forces()).max() < 1e-12
+    s.update_nodes_with_bc(1.0)
+    o.update_nodes_with_bc(1.0)
+    assert np.array_equal(s.nodes(), o.nodes())
+    assert s.update_state() == 0
+    s.close()
+
+
+@pytest.mark.parametrize("lam", [0.0, 0.5])
+def test_prescribed_bc_application(lam, decks_dir):
+    deck = feahip.Deck.load(os.path.join(decks_dir, "neohook_brick_analytical.sexp"))
+    s, o = make_pair(deck, mesh.deformed_state(deck.nodes, k1=1.02))
+    o.update_state(); o.create_stiffness(); o.create_residual_forces()
+    s.create_stiffness_and_residual()
+    o.apply_prescribed_bc(lam)
+    s.apply_prescribed_bc(lam)
+    off, idx, val = s.matrix_yale()
+    cmask = np.zeros(s.ndof, dtype=bool)
+    for n, t in zip(deck.presc_node, deck.presc_type):
+        for j in range(3):
+            if t & (1 << j):
+                cmask[3 * n + j] = True
+    rows = np.repeat(np.arange(s.ndof), np.diff(off))
+    cancelled = (cmask[rows] | cmask[idx]) & (rows != idx)
+    assert cancelled.sum() > 0 and np.all(val[cancelled] == 0)       # rows and columns zeroed exactly
+    assert np.all(o.values()[cancelled] == 0)
+    assert np.all(val[(rows == idx) & cmask[rows]] != 0)               # diagonal kept (fea_solver.c:1255)
+    assert rel(val, o.values()) < K_TOL
+    assert rel(s.forces(), o.forces()) < 1e-11     # f is a sum of cancelling element forces
+    s.close()
+
+
+def test_spmv_and_energy():
+    deck = mesh.bar_deck(dims=(3, 7, 3))
+    s, o = make_pair(deck, mesh.deformed_state(deck.nodes))
+    o.update_state(); o.create_stiffness()
+    s.create_stiffness()
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=s.ndof)
+    assert rel(s.spmv(x), o.spmv(x)) < 1e-13
+    s.close()
+
+
+@pytest.mark.parametrize("solver", [feahip.CG, feahip.PCG_ILU, feahip.CHOLESKY])
+def test_linear_solve_matches_direct_solver(solver):
+    deck = mesh.bar_deck(dims=(3, 8, 3))
+    s, o = make_pair(deck)
+    for obj in (s, o):
+        obj.update_nodes_with_bc(1.0)
+    o.update_state(); o.create_stiffness(); o.create_residual_forces(); o.apply_prescribed_bc(0.0)
+    s.create_stiffness_and_residual(); s.apply_prescribed_bc(0.0)
+    o.solve_slae(feahip.CHOLESKY)
+    it, res = s.solve_slae(solver, 1e-15, 20000)
+    assert it > 0 and res < 1e-14
+    assert rel(s.solution(), o.solution()) < U_TOL
+    assert s.energy() == pytest.approx(o.energy(), rel=1e-11)
+    cd = np.concatenate([[3 * n + j for j in range(3) if t & (1 << j)] for n, t in zip(deck.presc_node, deck.presc_type)])
+    assert np.all(s.solution()[cd] == 0)              # increments at prescribed dofs are exactly 0
+    s.close()
+
+
+def test_zero_rhs_solves_to_zero():
+    deck = mesh.bar_deck(dims=(2, 2, 2))
+    s = feahip.FeaSolver(deck)
+    s.create_stiffness_and_residual()
+    s.apply_prescribed_bc(0.0)
+    it, res = s.solve_slae(feahip.PCG_ILU, 1e-14, 100)
+    assert it == 0 and np.all(s.solution() == 0)
+    s.close()
+
+
+def run_newton_both(deck, steps, modified, solver=feahip.CHOLESKY):
+    s, o = make_pair(deck)
+    od, oits, otol = o.solve(steps, deck.max_newton_count, modified, deck.desired_tolerance, feahip.CHOLESKY)
+    sd, sits, stol = s.solve(load_increments=steps, modified_newton=modified, solver_type=solver)
+    return s, o, (sd, sits, stol), (od, oits, otol)
+
+
+def test_newton_on_reference_deck_matches_oracle(decks_dir):
+    """config 1: the shipped clamped deck with its own settings (modified
+    Newton, tolerance 1e-6 on <u,f>, direct solver).  Same iteration
+    sequence, same <u,f> per iteration, displacements within 1e-10."""
+    deck = feahip.Deck.load(os.path.join(decks_dir, "neohook_brick.sexp"))
+    s, o, (sd, sits, stol), (od, oits, otol) = run_newton_both(deck, 2, True)
+    assert sd == od == 2 and list(sits[:2]) == list(oits[:2]) == [13, 12]
+    assert np.abs(stol - otol).max() < 1e-10 * np.abs(otol).max()
+    du_s, du_o = s.nodes() - deck.nodes, o.nodes() - deck.nodes
+    assert rel(du_s, du_o) < U_TOL
+    assert rel(s.stresses(), o.stresses()) < 1e-9
+    s.close()
+
+
+def test_newton_a5_deck_matches_oracle(decks_dir):
+    deck = feahip.Deck.load(os.path.join(decks_dir, "a5_brick.sexp"))
+    s, o, (sd, sits, stol), (od, oits, otol) = run_newton_both(deck, 1, True)
+    assert sd == od == 1 and list(sits[:1]) == list(oits[:1]) == [7]
+    assert rel(s.nodes() - deck.nodes, o.nodes() - deck.nodes) < U_TOL
+    s.close()
+
+
+def test_full_newton_tet4_patch_test_closed_form():
+    """Rotation-free uniaxial recipe on linear tets: the Neo-Hookean closed
+    form of exact-solutions/uniaxial/uniaxial_neohookean_bonet.m is the exact
+    FE answer, at any mesh size."""
+    from test_oracle_closed_form import nh_closed_form
+    deck = mesh.bar_deck(dims=(4, 24, 4), recipe="uniaxial", dy=0.05, max_newton_count=8, desired_tolerance=1e-22,
+                         modified_newton=False, load_increments_count=2)
+    s = feahip.FeaSolver(deck)
+    done, its, tol = s.solve(solver_type=feahip.PCG_ILU, solver_tolerance=1e-15)
+    k1 = 1 + 2 * 0.05 / 6
+    k2, syy = nh_closed_form(k1)
+    S = s.stresses()
+    assert np.abs(S[:, 0, 1, 1] - syy).max() < 1e-9
+    A = deck.nodes.min(axis=0)
+    expect = A + (deck.nodes - A) * np.array([k2, k1, k2])
+    assert np.abs(s.nodes() - expect).max() < 1e-11
+    s.close()
+
+
+def test_host_driver_runs_the_deck(decks_dir, tmp_path):
+    """fea_solve() in libfeahost.so (the C mirror of solve()) drives the same
+    ABI and logs the reference's convergence lines."""
+    import ctypes as C
+    h = feahip.load_host_library()
+    deck = feahip.Deck.load(os.path.join(decks_dir, "neohook_brick.sexp"))
+    deck.load_increments_count = 1
+    fd = deck.to_struct()
+    ctx = C.c_void_p()
+    err = C.create_string_buffer(256)
+    assert h.fea_deck_create_solver(C.byref(fd), 0, C.byref(ctx), err, 256) == 0, err.value
+    xs = np.zeros((1, len(deck.nodes), 3))
+    steps = h.fea_solve(C.byref(fd), ctx, None, xs.ctypes.data_as(C.POINTER(C.c_double)), 1)
+    assert steps == 1
+    o = OracleSolver(deck)
+    o.solve(1, deck.max_newton_count, True, deck.desired_tolerance, feahip.CHOLESKY)
+    assert rel(xs[0] - deck.nodes, o.nodes() - deck.nodes) < U_TOL
+    feahip.load_library().feahip_destroy(ctx)
+
+
+def test_brick_fine_one_assembly(decks_dir, tmp_path):
+    """The largest shipped deck (22 934 TET10) with its BC ids shifted to
+    0-based (build-side correction): one assembly + BC."""
+    p = tmp_path / "brick_fine.sexp"
+    with gzip.open(os.path.join(decks_dir, "brick_fine.sexp.gz"), "rb") as src, open(p, "wb") as dst:
+        shutil.copyfileobj(src, dst)
+    deck = feahip.Deck.load(str(p))
+    deck.presc_node = (deck.presc_node - 1).astype(np.int32)
+    s = feahip.FeaSolver(deck)
+    s.update_nodes_with_bc(1.0)
+    s.create_stiffness_and_residual()
+    assert s.update_state() == 0                         # no inverted Gauss point with corrected ids
+    off, idx, val = s.matrix_yale()
+    assert len(val) == 8300196                           # scalar nnz of the deck
+    # spot-check 40 elements' worth of rows against the oracle's element matrices
+    o = OracleSolver(deck)
+    o.update_nodes_with_bc(1.0)
+    o.update_state()
+    import scipy.sparse as sp
+    K = sp.csr_matrix((val, idx, off), shape=(s.ndof, s.ndof))
+    sym = abs(K - K.T).max() / abs(K).max()
+    assert sym < 1e-12
+    t = np.zeros(s.ndof); t[1::3] = 1.0
+    assert np.abs(K @ t).max() < 1e-10 * abs(K).max()
+    s.close()
+
+
+def test_error_paths():
+    deck = mesh.bar_deck(dims=(1, 1, 1))
+    s = feahip.FeaSolver(deck)
+    with pytest.raises(feahip.FeaHipError, match="before stash"):
+        s.restore_stiffness()
+    with pytest.raises(feahip.FeaHipError, match="solver type"):
+        s.solve_slae(9, 1e-10, 10)
+    with pytest.raises(feahip.FeaHipError, match="strategy"):
+        s.set_assembly(7)
+    s.close()
+    bad = mesh.bar_deck(dims=(1, 1, 1))
+    bad.elements = bad.elements.copy()
+    bad.elements[0, 0] = 99
+    with pytest.raises(feahip.FeaHipError, match="outside"):
+        feahip.FeaSolver(bad)
+    bad = mesh.bar_deck(dims=(1, 1, 1))
+    bad.presc_node = bad.presc_node.copy()
+    bad.presc_node[0] = -4
+    with pytest.raises(feahip.FeaHipError, match="out of range"):
+        feahip.FeaSolver(bad)
+
+
+def test_inverted_elements_are_reported():
+    deck = mesh.bar_deck(dims=(2, 2, 2))
+    x = deck.nodes.copy()
+    x[deck.elements[0, 1]] = x[deck.elements[0, 0]] - (x[deck.elements[0, 1]] - x[deck.elements[0, 0]])
+    s = feahip.FeaSolver(deck)
+    s.set_nodes(x)
+    s.create_stiffness()
+    assert s.update_state() > 0
+    s.close()
