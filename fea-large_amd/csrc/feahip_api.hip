@@ -92,8 +92,9 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
     if ((rc = dev_upload(c, &c->d_incslot, hp.incslot.data(), hp.incslot.size()))) return rc;
   }
   if ((rc = dev_upload(c, &c->d_chunk, hp.chunk.data(), hp.chunk.size()))) return rc;
+  if ((rc = dev_upload(c, &c->d_diag, hp.diag.data(), hp.diag.size()))) return rc;
   c->aux_bytes = (long long)(hp.incptr.size() * 4 + hp.inc.size() * 4 + hp.incslot.size() +
-                             hp.chunk.size() * 4 + hp.rowptr.size() * 4);
+                             hp.chunk.size() * 4 + hp.rowptr.size() * 4 + hp.diag.size() * 4);
 
   if ((rc = dev_zeros(c, &c->d_K, (size_t)c->nnzb * 9))) return rc;
   if ((rc = dev_zeros(c, &c->d_f, (size_t)c->ndof))) return rc;
@@ -157,7 +158,7 @@ extern "C" void feahip_destroy(feahip_ctx *c)
 {
   if (!c) return;
   void *ptrs[] = {c->d_table, c->d_conn, c->d_X0, c->d_x, c->d_rowptr, c->d_colidx, c->d_K, c->d_Kstash,
-                  c->d_incptr, c->d_inc, c->d_incslot, c->d_chunk, c->d_f, c->d_u, c->d_r, c->d_p,
+                  c->d_incptr, c->d_inc, c->d_incslot, c->d_chunk, c->d_diag, c->d_f, c->d_u, c->d_r, c->d_p,
                   c->d_q, c->d_minv, c->d_part, c->d_scal, c->d_flag, c->d_cdof, c->d_cval,
                   c->d_dofmask, c->d_F, c->d_S};
   for (void *p : ptrs)

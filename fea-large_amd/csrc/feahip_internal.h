@@ -59,6 +59,7 @@ struct feahip_ctx {
   uint32_t *d_inc = nullptr;   // [npe*E]  elem | local<<28
   uint8_t *d_incslot = nullptr;// [npe*E][npe] slot of column conn[e][b] in row
   int *d_chunk = nullptr;      // [nchunks+1] first row of every chunk
+  int *d_diag = nullptr;       // [N] index of the diagonal block of every row
   // vectors (3N doubles)
   double *d_f = nullptr, *d_u = nullptr;
   double *d_r = nullptr, *d_p = nullptr, *d_q = nullptr, *d_minv = nullptr;
@@ -98,6 +99,7 @@ struct HostPattern {
   std::vector<uint32_t> inc;             // [npe*E]
   std::vector<uint8_t> incslot;          // [npe*E*npe]
   std::vector<int> chunk;                // chunk -> first row
+  std::vector<int> diag;                 // row -> index of its diagonal block
   int max_rowlen = 0;
 };
 int build_host_pattern(int N, int E, int npe, const int *conn, HostPattern &hp,

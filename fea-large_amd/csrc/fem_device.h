@@ -32,6 +32,7 @@ struct AsmArgs {
   const uint32_t *inc;
   const uint8_t *incslot;
   const int *chunk;
+  const int *diag;               // [N] diagonal block of every row
   int *bad;                      // counter of Gauss points with det J <= 0
   double *Fout, *Sout;           // state export
 };
@@ -53,12 +54,22 @@ __device__ __forceinline__ double fd_det3(const double m[3][3])
          m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
 }
 
+// 1/x by v_rcp_f64 and two Newton steps (~1 ulp); the IEEE division sequence
+// hipcc emits for 1.0/x is three times as long
+__device__ __forceinline__ double fd_rcp(double x)
+{
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
 // adjugate / det (dense_matrix.c:34-60 divides nine times; one reciprocal
 // here, the difference is 1 ulp per entry)
 __device__ __forceinline__ void fd_inv3(const double m[3][3], double r[3][3], double &det)
 {
   det = fd_det3(m);
-  double id = 1.0 / det;
+  const double id = fd_rcp(det);
   r[0][0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) * id;
   r[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) * id;
   r[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) * id;
@@ -131,7 +142,7 @@ __device__ __forceinline__ void gp_state(const double (&xe)[NPE][3], const doubl
     }
   fd_inv3(Fi, s.F, detFi);
   const double Jd = fd_det3(s.F);
-  const double iJ = 1.0 / Jd;
+  const double iJ = fd_rcp(Jd);
   if (model == FEAHIP_MODEL_COMPRESSIBLE_NEOHOOKEAN) {
     const double lnJ = log(Jd);
 #pragma unroll

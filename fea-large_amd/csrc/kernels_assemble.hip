@@ -84,15 +84,41 @@ void k_assemble_rowowner(AsmArgs A)
           fa[i] -= s.vol * (s.sig[i][0] * ga[0] + s.sig[i][1] * ga[1] + s.sig[i][2] * ga[2]);
       }
       if (DOK) {
+        // the diagonal block (b == la) is skipped: it comes from the row sum below
+        if constexpr (NPE == 4) {
+          // three off-diagonal blocks, b = la+1, la+2, la+3 (mod 4): all lanes
+          // stay active in every pass although their la differ
 #pragma unroll
-        for (int b = 0; b < NPE; ++b) {
-          double h[3], m[3], t[3], blk[9];
-          col_vectors(s.g[b], s.sig, s.l1, s.m1, s.vol, h, m, t);
-          block_ab(ga, h, m, t, blk);
-          double *dst = tK + rowoff + slot[b] * 9;
+          for (int k = 1; k < 4; ++k) {
+            const int b = (la + k) & 3;
+            double gb[3] = {s.g[0][0], s.g[0][1], s.g[0][2]};
+            int sl = slot[0];
 #pragma unroll
-          for (int q = 0; q < 9; ++q)
-            __hip_atomic_fetch_add(dst + q, blk[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int c = 1; c < 4; ++c) {
+              sl = (b == c) ? slot[c] : sl;
+#pragma unroll
+              for (int i = 0; i < 3; ++i) gb[i] = (b == c) ? s.g[c][i] : gb[i];
+            }
+            double h[3], m[3], t[3], blk[9];
+            col_vectors(gb, s.sig, s.l1, s.m1, s.vol, h, m, t);
+            block_ab(ga, h, m, t, blk);
+            double *dst = tK + rowoff + sl * 9;
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+              __hip_atomic_fetch_add(dst + q, blk[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        } else {
+#pragma unroll
+          for (int b = 0; b < NPE; ++b) {
+            if (b == la) continue;
+            double h[3], m[3], t[3], blk[9];
+            col_vectors(s.g[b], s.sig, s.l1, s.m1, s.vol, h, m, t);
+            block_ab(ga, h, m, t, blk);
+            double *dst = tK + rowoff + slot[b] * 9;
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+              __hip_atomic_fetch_add(dst + q, blk[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
         }
       }
     }
@@ -105,6 +131,18 @@ void k_assemble_rowowner(AsmArgs A)
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   if (DOK) {
+    // Shape functions sum to one, so sum_b grad N_b = 0 and every element's
+    // blocks of one row add up to zero: K_aa = -sum_{b != a} K_ab.  The
+    // diagonal block -- the one all visits of a row would collide on -- is
+    // therefore never added to; it is the negative sum of the finished row.
+    for (int t = lane; t < (r1 - r0) * 9; t += 64) {
+      const int r = r0 + t / 9, q = t % 9;
+      const int kb = A.rowptr[r] - b0, ke = A.rowptr[r + 1] - b0, kd = A.diag[r] - b0;
+      double acc = 0;
+      for (int k = kb; k < ke; ++k) acc += (k == kd) ? 0.0 : tK[k * 9 + q];
+      tK[kd * 9 + q] = -acc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     double *Kd = A.K + (size_t)b0 * 9;
     for (int t = lane; t < nb * 9; t += 64) Kd[t] = tK[t];
   }
@@ -221,7 +259,7 @@ static AsmArgs make_args(feahip_ctx *c)
   A.tab = c->d_table; A.conn = c->d_conn; A.X0 = c->d_X0; A.x = c->d_x;
   A.rowptr = c->d_rowptr; A.colidx = c->d_colidx; A.K = c->d_K; A.f = c->d_f;
   A.incptr = c->d_incptr; A.inc = c->d_inc; A.incslot = c->d_incslot;
-  A.chunk = c->d_chunk; A.bad = c->d_flag + 1;
+  A.chunk = c->d_chunk; A.diag = c->d_diag; A.bad = c->d_flag + 1;
   A.Fout = c->d_F; A.Sout = c->d_S;
   return A;
 }

@@ -89,26 +89,6 @@ int build_host_pattern(int N, int E, int npe, const int *conn, HostPattern &hp,
     }
   });
 
-  // slot of every (incidence, local column node) inside its block row
-  if (maxlen <= 255) {
-    hp.incslot.resize((size_t)E * npe * npe);
-    parallel_ranges(N, [&](int lo, int hi, int) {
-      for (int a = lo; a < hi; ++a) {
-        const int *cb = hp.colidx.data() + hp.rowptr[a];
-        const int *ce = hp.colidx.data() + hp.rowptr[a + 1];
-        for (int p = hp.incptr[a]; p < hp.incptr[a + 1]; ++p) {
-          int e = (int)(hp.inc[p] & 0x0FFFFFFFu);
-          for (int k = 0; k < npe; ++k) {
-            int b = conn[(size_t)e * npe + k];
-            hp.incslot[(size_t)p * npe + k] = (uint8_t)(std::lower_bound(cb, ce, b) - cb);
-          }
-        }
-      }
-    });
-  } else {
-    hp.incslot.clear();   // row-owner assembly unavailable; atomic path only
-  }
-
   // chunks of consecutive rows, each small enough for one wave's LDS tile
   hp.chunk.clear();
   hp.chunk.push_back(0);
@@ -122,5 +102,53 @@ int build_host_pattern(int N, int E, int npe, const int *conn, HostPattern &hp,
     rows++; blocks += len;
   }
   hp.chunk.push_back(N);
+  const int nchunks = (int)hp.chunk.size() - 1;
+
+  // position of the diagonal block of every row
+  hp.diag.resize((size_t)N);
+  parallel_ranges(N, [&](int lo, int hi, int) {
+    for (int a = lo; a < hi; ++a) {
+      const int *cb = hp.colidx.data() + hp.rowptr[a];
+      const int *ce = hp.colidx.data() + hp.rowptr[a + 1];
+      hp.diag[a] = hp.rowptr[a] + (int)(std::lower_bound(cb, ce, a) - cb);
+    }
+  });
+
+  // Inside a chunk the (row, element) visits are dealt round-robin over the
+  // rows: the 64 lanes of one pass then work on as many different rows as the
+  // chunk has, which keeps LDS adds to one address few (same-address
+  // ds_add_f64 serialise, ~11 clk per extra lane on gfx950).
+  parallel_ranges(nchunks, [&](int lo, int hi, int) {
+    std::vector<uint32_t> tmp;
+    for (int ch = lo; ch < hi; ++ch) {
+      const int r0 = hp.chunk[ch], r1 = hp.chunk[ch + 1];
+      const int p0 = hp.incptr[r0], p1 = hp.incptr[r1];
+      tmp.assign(hp.inc.begin() + p0, hp.inc.begin() + p1);
+      int out = p0, maxlen = 0;
+      for (int r = r0; r < r1; ++r) maxlen = std::max(maxlen, hp.incptr[r + 1] - hp.incptr[r]);
+      for (int k = 0; k < maxlen; ++k)
+        for (int r = r0; r < r1; ++r)
+          if (k < hp.incptr[r + 1] - hp.incptr[r]) hp.inc[out++] = tmp[hp.incptr[r] - p0 + k];
+    }
+  });
+
+  // slot of every (visit, local column node) inside the visit's block row
+  if (maxlen <= 255) {
+    hp.incslot.resize((size_t)E * npe * npe);
+    parallel_ranges((int)((long long)E * npe > 0x7FFFFFFF ? 0x7FFFFFFF : (long long)E * npe), [&](int lo, int hi, int) {
+      for (int p = lo; p < hi; ++p) {
+        const int e = (int)(hp.inc[p] & 0x0FFFFFFFu), la = (int)(hp.inc[p] >> 28);
+        const int a = conn[(size_t)e * npe + la];
+        const int *cb = hp.colidx.data() + hp.rowptr[a];
+        const int *ce = hp.colidx.data() + hp.rowptr[a + 1];
+        for (int k = 0; k < npe; ++k) {
+          int b = conn[(size_t)e * npe + k];
+          hp.incslot[(size_t)p * npe + k] = (uint8_t)(std::lower_bound(cb, ce, b) - cb);
+        }
+      }
+    });
+  } else {
+    hp.incslot.clear();   // row-owner assembly unavailable; atomic path only
+  }
   return FEAHIP_OK;
 }
