@@ -96,6 +96,20 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
   c->aux_bytes = (long long)(hp.incptr.size() * 4 + hp.inc.size() * 4 + hp.incslot.size() +
                              hp.chunk.size() * 4 + hp.rowptr.size() * 4 + hp.diag.size() * 4);
 
+  if (c->linear_tet && gauss_count == 1) {
+    HostPatches pt;
+    build_host_patches(n_nodes, n_elems, elements, hp, pt);
+    if (pt.ok) {
+      if ((rc = dev_upload(c, &c->d_pdesc, pt.desc.data(), pt.desc.size()))) return rc;
+      if ((rc = dev_upload(c, &c->d_pnode, pt.pnode.data(), pt.pnode.size()))) return rc;
+      if ((rc = dev_upload(c, &c->d_pelem, pt.pelem.data(), pt.pelem.size()))) return rc;
+      if ((rc = dev_upload(c, &c->d_pent, pt.pent.data(), pt.pent.size()))) return rc;
+      if ((rc = dev_upload(c, &c->d_pbptr, pt.pbptr.data(), pt.pbptr.size()))) return rc;
+      c->have_patches = true;
+      c->patch_bytes = (long long)(pt.desc.size() * sizeof(PatchDesc) + pt.pnode.size() * 4 +
+                                   pt.pelem.size() * 2 + pt.pent.size() * 2 + pt.pbptr.size() * 2);
+    }
+  }
   if ((rc = dev_zeros(c, &c->d_K, (size_t)c->nnzb * 9))) return rc;
   if ((rc = dev_zeros(c, &c->d_f, (size_t)c->ndof))) return rc;
   if ((rc = dev_zeros(c, &c->d_u, (size_t)c->ndof))) return rc;
@@ -158,7 +172,7 @@ extern "C" void feahip_destroy(feahip_ctx *c)
 {
   if (!c) return;
   void *ptrs[] = {c->d_table, c->d_conn, c->d_X0, c->d_x, c->d_rowptr, c->d_colidx, c->d_K, c->d_Kstash,
-                  c->d_incptr, c->d_inc, c->d_incslot, c->d_chunk, c->d_diag, c->d_f, c->d_u, c->d_r, c->d_p,
+                  c->d_incptr, c->d_inc, c->d_incslot, c->d_chunk, c->d_diag, c->d_pdesc, c->d_pnode, c->d_pelem, c->d_pent, c->d_pbptr, c->d_f, c->d_u, c->d_r, c->d_p,
                   c->d_q, c->d_minv, c->d_part, c->d_scal, c->d_flag, c->d_cdof, c->d_cval,
                   c->d_dofmask, c->d_F, c->d_S};
   for (void *p : ptrs)
@@ -181,7 +195,7 @@ extern "C" int feahip_sync(feahip_ctx *c)
 extern "C" int feahip_set_assembly(feahip_ctx *c, int strategy)
 {
   CTX_GUARD(c);
-  if (strategy < FEAHIP_ASM_AUTO || strategy > FEAHIP_ASM_ATOMIC) { c->err = "unknown assembly strategy"; return FEAHIP_EINVAL; }
+  if (strategy < FEAHIP_ASM_AUTO || strategy > FEAHIP_ASM_PATCH) { c->err = "unknown assembly strategy"; return FEAHIP_EINVAL; }
   c->strategy = strategy;
   return FEAHIP_OK;
 }
@@ -459,6 +473,6 @@ extern "C" int feahip_sizes(feahip_ctx *c, long long *o)
 {
   if (!c || !o) return FEAHIP_EINVAL;
   o[0] = c->N; o[1] = c->E; o[2] = c->npe; o[3] = c->G; o[4] = c->nnzb; o[5] = c->nchunks;
-  o[6] = c->aux_bytes; o[7] = c->max_rowlen;
+  o[6] = c->have_patches ? c->patch_bytes + (long long)(c->N + 1) * 8 : c->aux_bytes; o[7] = c->max_rowlen;
   return FEAHIP_OK;
 }

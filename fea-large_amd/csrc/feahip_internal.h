@@ -25,6 +25,7 @@ struct ElemTable {            // element plug-in, tabulated by the host
   double dN[FEA_MAX_GAUSS][3][FEA_MAX_NPE];
 };
 
+struct PatchDesc;
 struct feahip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -60,6 +61,12 @@ struct feahip_ctx {
   uint8_t *d_incslot = nullptr;// [npe*E][npe] slot of column conn[e][b] in row
   int *d_chunk = nullptr;      // [nchunks+1] first row of every chunk
   int *d_diag = nullptr;       // [N] index of the diagonal block of every row
+  // PATCH assembly maps (linear tetrahedra)
+  bool have_patches = false;
+  PatchDesc *d_pdesc = nullptr;
+  int *d_pnode = nullptr;
+  uint16_t *d_pelem = nullptr, *d_pent = nullptr, *d_pbptr = nullptr;
+  long long patch_bytes = 0;
   // vectors (3N doubles)
   double *d_f = nullptr, *d_u = nullptr;
   double *d_r = nullptr, *d_p = nullptr, *d_q = nullptr, *d_minv = nullptr;
@@ -105,7 +112,30 @@ struct HostPattern {
 int build_host_pattern(int N, int E, int npe, const int *conn, HostPattern &hp,
                        std::string &err);
 
-// launchers (kernels_assemble.hip / kernels_solve.hip)
+// patches.cpp -- per-chunk maps of the PATCH assembly (kernels_patch.hip)
+#define FEA_PATCH_MAX_NODES 128      // unique nodes touched by one patch (LDS coordinate tile)
+#define FEA_PATCH_MAX_ENTRIES 1536   // off-diagonal block contributions of one patch
+#define FEA_PATCH_MAX_ELEMS 2048     // 11-bit element index inside an entry
+struct PatchDesc {                   // 48 bytes, one per chunk
+  int r0, r1;                        // rows [r0, r1)
+  int b0, nb;                        // blocks [b0, b0+nb) of the CSR
+  int node_off, nnode;               // into pnode
+  int elem_off, nelem;               // into pelem
+  int ent_off, nent;                 // into pent
+  int bptr_off, pad;                 // into pbptr (nb+1 entries)
+};
+struct HostPatches {
+  std::vector<PatchDesc> desc;
+  std::vector<int> pnode;            // global node id of every patch-local node
+  std::vector<uint16_t> pelem;       // [..][4] patch-local node ids of every patch element
+  std::vector<uint16_t> pent;        // elem(11) | la(2)<<11 | lb(2)<<13 | first(1)<<15
+  std::vector<uint16_t> pbptr;       // per patch nb+1 offsets into its entries
+  bool ok = false;                   // every chunk fits the limits above
+};
+void build_host_patches(int N, int E, const int *conn, const HostPattern &hp, HostPatches &out);
+
+// launchers (kernels_assemble.hip / kernels_patch.hip / kernels_solve.hip)
+int launch_assemble_patch(feahip_ctx *c, bool doF);
 int launch_assemble(feahip_ctx *c, bool doK, bool doF);
 int launch_state_export(feahip_ctx *c);
 int launch_apply_bc(feahip_ctx *c, double lambda);

@@ -288,7 +288,17 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
   AsmArgs A = make_args(c);
   const bool rowowner_ok = c->d_incslot != nullptr && c->max_rowlen <= FEA_CHUNK_BLOCKS;
   int strat = c->strategy;
+  // AUTO: the visit (row-owner) kernel; PATCH is the bitwise-reproducible variant, 1.8x slower today
   if (strat == FEAHIP_ASM_AUTO) strat = rowowner_ok ? FEAHIP_ASM_ROWOWNER : FEAHIP_ASM_ATOMIC;
+  if (strat == FEAHIP_ASM_PATCH && !doK) strat = FEAHIP_ASM_ROWOWNER;   // residual alone: visit kernel
+  if (strat == FEAHIP_ASM_PATCH) {
+    if (!c->have_patches) {
+      c->err = "patch assembly needs linear tetrahedra whose chunks fit the LDS tiles";
+      return FEAHIP_EINVAL;
+    }
+    FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));
+    return launch_assemble_patch(c, doF);
+  }
   if (strat == FEAHIP_ASM_ROWOWNER && !rowowner_ok) {
     c->err = "row-owner assembly needs block rows of at most " +
              std::to_string(FEA_CHUNK_BLOCKS) + " blocks (mesh has " +
