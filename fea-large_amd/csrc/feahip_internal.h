@@ -18,7 +18,7 @@
 #define FEA_WAVES_PER_WG 4
 // grid used by the vector / reduction kernels: their per-block partial sums
 // are re-reduced by every block of the consuming kernel.
-#define FEA_RED_BLOCKS 1024
+#define FEA_RED_BLOCKS 2048
 
 struct ElemTable {            // element plug-in, tabulated by the host
   double w[FEA_MAX_GAUSS];

@@ -84,7 +84,8 @@ __device__ __forceinline__ void fd_inv3(const double m[3][3], double r[3][3], do
 // State of one Gauss point from the element's current (xe) and initial (Xe)
 // node coordinates.  LINTET: constant-strain tetrahedron, dN/dxi is the
 // fixed table {-1,1,0,0; -1,0,1,0; -1,0,0,1} and is folded into the algebra.
-template <int NPE, bool LINTET>
+// NEEDF = false lets the Neo-Hookean branch skip F itself (see below).
+template <int NPE, bool LINTET, bool NEEDF = true>
 __device__ __forceinline__ void gp_state(const double (&xe)[NPE][3], const double (&Xe)[NPE][3],
                                          const ElemTable *tab, int gp, int model,
                                          double lambda, double mu, GPState<NPE> &s)
@@ -140,6 +141,35 @@ __device__ __forceinline__ void gp_state(const double (&xe)[NPE][3], const doubl
       }
       Fi[i][j] = acc;
     }
+  if constexpr (!NEEDF) {
+    if (model == FEAHIP_MODEL_COMPRESSIBLE_NEOHOOKEAN) {
+      // sigma needs only B = F F' = (Fi' Fi)^-1 and J = 1/det Fi: invert the
+      // symmetric Fi'Fi by its adjugate (det = det(Fi)^2) instead of
+      // inverting Fi and multiplying out -- about half the flops, no F.
+      detFi = fd_det3(Fi);
+      const double Jd = fd_rcp(detFi);           // J = det F
+      const double lnJ = -log(detFi);
+      double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        c00 += Fi[i][0] * Fi[i][0]; c01 += Fi[i][0] * Fi[i][1]; c02 += Fi[i][0] * Fi[i][2];
+        c11 += Fi[i][1] * Fi[i][1]; c12 += Fi[i][1] * Fi[i][2]; c22 += Fi[i][2] * Fi[i][2];
+      }
+      // sigma = mu/J (B - I) + lambda lnJ/J I,  B = adj(C) J^2,  1/J = det Fi
+      const double mJ = mu * Jd;                  // mu J = (mu/J) J^2
+      const double dg = (mu - lambda * lnJ) * detFi;
+      s.sig[0][0] = mJ * (c11 * c22 - c12 * c12) - dg;
+      s.sig[1][1] = mJ * (c00 * c22 - c02 * c02) - dg;
+      s.sig[2][2] = mJ * (c00 * c11 - c01 * c01) - dg;
+      s.sig[0][1] = s.sig[1][0] = mJ * (c02 * c12 - c01 * c22);
+      s.sig[0][2] = s.sig[2][0] = mJ * (c01 * c12 - c02 * c11);
+      s.sig[1][2] = s.sig[2][1] = mJ * (c01 * c02 - c00 * c12);
+      s.l1 = lambda * detFi;
+      s.m1 = dg;
+      s.vol = tab->w[gp] * fabs(s.detJ);
+      return;
+    }
+  }
   fd_inv3(Fi, s.F, detFi);
   const double Jd = fd_det3(s.F);
   const double iJ = fd_rcp(Jd);
@@ -214,13 +244,20 @@ __device__ __forceinline__ void block_ab(const double ga[3], const double h[3], 
       out[3 * i + j] = ga[i] * h[j] + ga[j] * m[i] + ((i == j) ? d : 0.0);
 }
 
+// rot (NPE == 4 only): local node k of the result is local node k XOR rot of
+// the stored element
 template <int NPE>
 __device__ __forceinline__ void load_element(const AsmArgs &A, int e, int (&nd)[NPE],
-                                             double (&xe)[NPE][3], double (&Xe)[NPE][3])
+                                             double (&xe)[NPE][3], double (&Xe)[NPE][3], int rot = 0)
 {
   if constexpr (NPE == 4) {
     const int4 c = *reinterpret_cast<const int4 *>(A.conn + (size_t)e * 4);
-    nd[0] = c.x; nd[1] = c.y; nd[2] = c.z; nd[3] = c.w;
+    const int m[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int src = k ^ rot;
+      nd[k] = (src == 0) ? m[0] : (src == 1) ? m[1] : (src == 2) ? m[2] : m[3];
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < NPE; ++k) nd[k] = A.conn[(size_t)e * NPE + k];

@@ -26,6 +26,7 @@
 // ------------------------------------------------------------------------
 // row-owner
 // ------------------------------------------------------------------------
+// 4 waves per SIMD (<= 128 VGPRs) for 4-node elements; 10-node elements need the whole file
 template <int NPE, bool LINTET, bool DOK, bool DOF>
 __global__ __launch_bounds__(64 * FEA_WAVES_PER_WG)
 void k_assemble_rowowner(AsmArgs A)
@@ -52,10 +53,16 @@ void k_assemble_rowowner(AsmArgs A)
     const int e = (int)(w & 0x0FFFFFFFu), la = (int)(w >> 28);
     int nd[NPE];
     double xe[NPE][3], Xe[NPE][3];
-    load_element<NPE>(A, e, nd, xe, Xe);
+    // NPE == 4: the element is presented with its local nodes renumbered
+    // k -> k XOR la (an even permutation: orientation and every tensor stay
+    // what they are), so the row node is always local node 0 and nothing
+    // below needs a per-lane select on doubles.
+    load_element<NPE>(A, e, nd, xe, Xe, NPE == 4 ? la : 0);
     int a = nd[0];
+    if constexpr (NPE != 4) {
 #pragma unroll
-    for (int k = 1; k < NPE; ++k) a = (la == k) ? nd[k] : a;
+      for (int k = 1; k < NPE; ++k) a = (la == k) ? nd[k] : a;
+    }
     int slot[NPE];
     if (DOK) {
       if constexpr (NPE == 4) {
@@ -70,14 +77,16 @@ void k_assemble_rowowner(AsmArgs A)
     double fa[3] = {0, 0, 0};
     for (int gp = 0; gp < A.G; ++gp) {
       GPState<NPE> s;
-      gp_state<NPE, LINTET>(xe, Xe, A.tab, gp, A.model, A.lambda, A.mu, s);
+      gp_state<NPE, LINTET, false>(xe, Xe, A.tab, gp, A.model, A.lambda, A.mu, s);
       if (!(s.detJ > 0.0) && DOK && la == 0) atomicAdd(A.bad, 1);
       if (s.detJ == 0.0) continue;      // reference keeps no gradient then (fea_solver.c:697)
       double ga[3] = {s.g[0][0], s.g[0][1], s.g[0][2]};
+      if constexpr (NPE != 4) {
 #pragma unroll
-      for (int k = 1; k < NPE; ++k)
+        for (int k = 1; k < NPE; ++k)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) ga[i] = (la == k) ? s.g[k][i] : ga[i];
+          for (int i = 0; i < 3; ++i) ga[i] = (la == k) ? s.g[k][i] : ga[i];
+      }
       if (DOF) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -86,23 +95,13 @@ void k_assemble_rowowner(AsmArgs A)
       if (DOK) {
         // the diagonal block (b == la) is skipped: it comes from the row sum below
         if constexpr (NPE == 4) {
-          // three off-diagonal blocks, b = la+1, la+2, la+3 (mod 4): all lanes
-          // stay active in every pass although their la differ
+          // three off-diagonal blocks: local columns 1..3 of the renumbered element
 #pragma unroll
           for (int k = 1; k < 4; ++k) {
-            const int b = (la + k) & 3;
-            double gb[3] = {s.g[0][0], s.g[0][1], s.g[0][2]};
-            int sl = slot[0];
-#pragma unroll
-            for (int c = 1; c < 4; ++c) {
-              sl = (b == c) ? slot[c] : sl;
-#pragma unroll
-              for (int i = 0; i < 3; ++i) gb[i] = (b == c) ? s.g[c][i] : gb[i];
-            }
             double h[3], m[3], t[3], blk[9];
-            col_vectors(gb, s.sig, s.l1, s.m1, s.vol, h, m, t);
+            col_vectors(s.g[k], s.sig, s.l1, s.m1, s.vol, h, m, t);
             block_ab(ga, h, m, t, blk);
-            double *dst = tK + rowoff + sl * 9;
+            double *dst = tK + rowoff + slot[k] * 9;
 #pragma unroll
             for (int q = 0; q < 9; ++q)
               __hip_atomic_fetch_add(dst + q, blk[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

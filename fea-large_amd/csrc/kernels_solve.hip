@@ -155,37 +155,50 @@ int launch_update_nodes_solution(feahip_ctx *c, const double *d_uv)
 // ------------------------------------------------------------------------
 // SpMV  y = K x  (+ optional partial sums of dotwith . y)
 //
-// One wave owns a chunk of consecutive block rows, the same chunks as the
-// assembly.  The chunk's values are one contiguous run in HBM: the wave
-// streams them into LDS with fully coalesced loads, then lane k forms the
-// 3-vector K_k x_col(k) of block k (the x gather is spread over all 64
-// lanes), and lane (row,i) adds up its row's partial products in block
-// order.  No atomics; HBM sees each matrix byte once.
+// One wave owns a chunk of consecutive block rows (the assembly's chunks): a
+// contiguous run of at most 128 3x3 blocks.  Lane k takes blocks k and k+64:
+// it loads its blocks' nine values, their column index and the three x
+// entries they multiply -- all 26 loads of a lane are independent and in
+// flight together, nothing is staged -- and leaves the 3-vector K_k x_col(k)
+// in LDS; lane (row,i) then adds up its row's partial products in block
+// order.  No atomics, fixed summation order; HBM sees each matrix byte once
+// (the 72-byte blocks of neighbouring lanes share cache lines, so the nine
+// strided loads of a wave hit L1 after the first touch).
 // ------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
 void k_spmv(int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx, const double *K,
             const double *x, double *y, const double *dotwith, double *part, const int *flag)
 {
-  __shared__ double sV[FEA_WAVES_PER_WG][FEA_CHUNK_BLOCKS * 9];
   __shared__ double sP[FEA_WAVES_PER_WG][FEA_CHUNK_BLOCKS * 3];
   __shared__ double scratch[5];
   if (flag && flag[0] != 0) return;          // solve already converged (uniform)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double *tV = sV[wave], *tP = sP[wave];
+  double *tP = sP[wave];
   double dsum = 0;
   for (int ch = chunk0 + blockIdx.x * FEA_WAVES_PER_WG + wave; ch < chunk0 + nchunks; ch += gridDim.x * FEA_WAVES_PER_WG) {
     const int r0 = chunk[ch], r1 = chunk[ch + 1];
     const int b0 = rowptr[r0], nb = rowptr[r1] - b0;
-    const double *Kc = K + (size_t)b0 * 9;
-    for (int t = lane; t < nb * 9; t += 64) tV[t] = Kc[t];
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    for (int k = lane; k < nb; k += 64) {
-      const int col = colidx[b0 + k];
-      const double x0 = x[(size_t)col * 3], x1 = x[(size_t)col * 3 + 1], x2 = x[(size_t)col * 3 + 2];
-      const double *v = tV + k * 9;
-      tP[k * 3 + 0] = v[0] * x0 + v[1] * x1 + v[2] * x2;
-      tP[k * 3 + 1] = v[3] * x0 + v[4] * x1 + v[5] * x2;
-      tP[k * 3 + 2] = v[6] * x0 + v[7] * x1 + v[8] * x2;
+    double v[2][9], xv[2][3];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = lane + 64 * h;
+      const bool on = k < nb;
+      const int kk = on ? b0 + k : b0;
+      const int col = colidx[kk];
+      const double *vp = K + (size_t)kk * 9;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) v[h][q] = vp[q];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) xv[h][i] = x[(size_t)col * 3 + i];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = lane + 64 * h;
+      if (k < nb) {
+        tP[k * 3 + 0] = v[h][0] * xv[h][0] + v[h][1] * xv[h][1] + v[h][2] * xv[h][2];
+        tP[k * 3 + 1] = v[h][3] * xv[h][0] + v[h][4] * xv[h][1] + v[h][5] * xv[h][2];
+        tP[k * 3 + 2] = v[h][6] * xv[h][0] + v[h][7] * xv[h][1] + v[h][8] * xv[h][2];
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     for (int t = lane; t < (r1 - r0) * 3; t += 64) {

@@ -142,7 +142,9 @@ int build_host_pattern(int N, int E, int npe, const int *conn, HostPattern &hp,
         const int *cb = hp.colidx.data() + hp.rowptr[a];
         const int *ce = hp.colidx.data() + hp.rowptr[a + 1];
         for (int k = 0; k < npe; ++k) {
-          int b = conn[(size_t)e * npe + k];
+          // 4-node elements are visited with local node k XOR la in position k
+          // (row node first, kernels_assemble.hip); slots are stored in that order
+          int b = conn[(size_t)e * npe + (npe == 4 ? (k ^ la) : k)];
           hp.incslot[(size_t)p * npe + k] = (uint8_t)(std::lower_bound(cb, ce, b) - cb);
         }
       }
