@@ -169,7 +169,7 @@ def main():
                        "sharding": f"block rows in {world} slab(s) across y"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_assemble_rowowner", "algorithmic_bytes_per_launch": B},
+                         "kernel": "k_assemble_visit" if not args.quadratic else "k_assemble_rowowner", "algorithmic_bytes_per_launch": B},
             "extras": extras,
         }
         if args.cpu_sample > 0 and world == 1:

@@ -67,6 +67,12 @@ struct feahip_ctx {
   int *d_pnode = nullptr;
   uint16_t *d_pelem = nullptr, *d_pent = nullptr, *d_pbptr = nullptr;
   long long patch_bytes = 0;
+  // LDS-staged visit assembly maps (linear tetrahedra)
+  bool have_visits = false;
+  struct VisitDesc *d_vdesc = nullptr;
+  int *d_vnode = nullptr;
+  uint32_t *d_vrec = nullptr;
+  long long visit_bytes = 0;
   // vectors (3N doubles)
   double *d_f = nullptr, *d_u = nullptr;
   double *d_r = nullptr, *d_p = nullptr, *d_q = nullptr, *d_minv = nullptr;
@@ -133,6 +139,25 @@ struct HostPatches {
   bool ok = false;                   // every chunk fits the limits above
 };
 void build_host_patches(int N, int E, const int *conn, const HostPattern &hp, HostPatches &out);
+
+// LDS-staged visit assembly (kernels_visit.hip): per chunk, the nodes its
+// elements touch (owned rows first) and one 8-byte record per (row, element)
+// visit: 4 chunk-local node ids (row node first) + 3 column slots.
+#define FEA_VISIT_MAX_NODES 128
+#define FEA_VISIT_MAX_ROUNDS 6
+struct VisitDesc {                   // 32 bytes, one per chunk
+  int r0, r1, b0, nb;
+  int node_off, nnode;               // into vnode
+  int visit_off, nvisit;             // into vrec (same numbering as the inc array)
+};
+struct HostVisits {
+  std::vector<VisitDesc> desc;
+  std::vector<int> vnode;
+  std::vector<uint32_t> vrec;        // [2 * visits]: ids (4 x u8), slots (u8: 0, s1, s2, s3)
+  bool ok = false;
+};
+void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, HostVisits &out);
+int launch_assemble_visit(feahip_ctx *c, bool doK, bool doF);
 
 // launchers (kernels_assemble.hip / kernels_patch.hip / kernels_solve.hip)
 int launch_assemble_patch(feahip_ctx *c, bool doF);

@@ -287,8 +287,18 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
   AsmArgs A = make_args(c);
   const bool rowowner_ok = c->d_incslot != nullptr && c->max_rowlen <= FEA_CHUNK_BLOCKS;
   int strat = c->strategy;
-  // AUTO: the visit (row-owner) kernel; PATCH is the bitwise-reproducible variant, 1.8x slower today
-  if (strat == FEAHIP_ASM_AUTO) strat = rowowner_ok ? FEAHIP_ASM_ROWOWNER : FEAHIP_ASM_ATOMIC;
+  // AUTO: row-owner visits, with LDS-staged coordinates where the maps exist (linear tets);
+  // PATCH is the bitwise-reproducible variant, slower today
+  if (strat == FEAHIP_ASM_AUTO)
+    strat = c->have_visits ? FEAHIP_ASM_STAGED : (rowowner_ok ? FEAHIP_ASM_ROWOWNER : FEAHIP_ASM_ATOMIC);
+  if (strat == FEAHIP_ASM_STAGED) {
+    if (!c->have_visits) {
+      c->err = "staged assembly needs linear tetrahedra whose chunks fit the LDS tiles";
+      return FEAHIP_EINVAL;
+    }
+    if (doK) FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));
+    return launch_assemble_visit(c, doK, doF);
+  }
   if (strat == FEAHIP_ASM_PATCH && !doK) strat = FEAHIP_ASM_ROWOWNER;   // residual alone: visit kernel
   if (strat == FEAHIP_ASM_PATCH) {
     if (!c->have_patches) {

@@ -1,0 +1,153 @@
+// kernels_visit.hip -- stiffness / residual assembly of linear tetrahedra
+// with node coordinates and connectivity staged through LDS.
+//
+// Same row-owner idea as kernels_assemble.hip (one wave owns a chunk of
+// consecutive block rows, walks the (row node, element) visits of those rows,
+// sums the row's 3x3 blocks in an LDS tile with ds_add_f64, writes every CSR
+// value once).  What changes is where the data come from.  The visit kernel
+// of kernels_assemble.hip chases inc -> conn -> coordinates -> rowptr through
+// global memory in every pass of 64 visits: about twelve dependent memory
+// latencies per chunk against ~2 us of arithmetic, so the wave sits stalled.
+// Here the host has prepared, per chunk,
+//   vnode : the nodes its elements touch, owned rows first  (coalesced read)
+//   vrec  : per visit 4 chunk-local node ids, row node first, and the 3
+//           column slots                              (8 B, coalesced read)
+// so the wave (1) gathers the coordinates of ~70 nodes into LDS once, (2)
+// reads everything else from LDS: three dependent latencies per chunk.
+// The global element->node map is not read at all.
+// Replaces fea_solver.c:873-883 / 863-870 for TETRAHEDRA4 meshes.
+#include "fem_device.h"
+#include <cstdlib>
+
+struct VisitArgs {
+  int chunk0, nchunks, model;
+  double lambda, mu;
+  const ElemTable *tab;
+  const VisitDesc *desc;
+  const int *vnode;
+  const uint2 *vrec;
+  const double *X0, *x;          // [N][4]
+  const int *rowptr, *diag;
+  double *K, *f;
+  int *bad;
+  int dbg;                       // timing experiments only (FEAHIP_DBG): 1 = conflict-free K adds, 2 = no f adds
+};
+
+template <bool DOK, bool DOF>
+__global__ __launch_bounds__(64)
+void k_assemble_visit(VisitArgs A)
+{
+  __shared__ double sC[FEA_VISIT_MAX_NODES * 6];       // x, X0 of the chunk's nodes
+  __shared__ double sK[DOK ? FEA_CHUNK_BLOCKS * 9 : 1];
+  __shared__ double sF[FEA_CHUNK_ROWS * 3];
+  __shared__ int sRow[FEA_CHUNK_ROWS + 1];             // first block of every row, relative to b0
+  __shared__ int sDiag[FEA_CHUNK_ROWS];
+  const int lane = threadIdx.x;
+  const VisitDesc d = A.desc[A.chunk0 + blockIdx.x];
+  const int nrows = d.r1 - d.r0;
+
+  uint2 rec = make_uint2(0, 0);
+  if (lane < d.nvisit) rec = A.vrec[d.visit_off + lane];
+  if (lane <= nrows) sRow[lane] = A.rowptr[d.r0 + lane] - d.b0;
+  if (lane < nrows) sDiag[lane] = A.diag[d.r0 + lane] - d.b0;
+  for (int i = lane; i < d.nnode; i += 64) {
+    const size_t n = (size_t)A.vnode[d.node_off + i];
+    const double2 a0 = *reinterpret_cast<const double2 *>(A.x + n * 4);
+    const double2 a1 = *reinterpret_cast<const double2 *>(A.x + n * 4 + 2);
+    const double2 c0 = *reinterpret_cast<const double2 *>(A.X0 + n * 4);
+    const double2 c1 = *reinterpret_cast<const double2 *>(A.X0 + n * 4 + 2);
+    double *o = sC + i * 6;
+    o[0] = a0.x; o[1] = a0.y; o[2] = a1.x; o[3] = c0.x; o[4] = c0.y; o[5] = c1.x;
+  }
+  if (DOK)
+    for (int t = lane; t < d.nb * 9; t += 64) sK[t] = 0.0;
+  if (DOF)
+    for (int t = lane; t < nrows * 3; t += 64) sF[t] = 0.0;
+  __syncthreads();
+
+  for (int p = lane; p - lane < d.nvisit; p += 64) {
+    // record of the next pass, in flight while this one computes
+    uint2 nxt = make_uint2(0, 0);
+    if (p + 64 < d.nvisit) nxt = A.vrec[d.visit_off + p + 64];
+    if (p < d.nvisit) {
+      const unsigned ids = rec.x, sl = rec.y;
+      const int n0 = ids & 255u, n1 = (ids >> 8) & 255u, n2 = (ids >> 16) & 255u, n3 = ids >> 24;
+      const int nd[4] = {n0, n1, n2, n3};
+      double xe[4][3], Xe[4][3];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double *cc = sC + nd[k] * 6;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { xe[k][j] = cc[j]; Xe[k][j] = cc[3 + j]; }
+      }
+      GPState<4> s;
+      gp_state<4, true, false>(xe, Xe, A.tab, 0, A.model, A.lambda, A.mu, s);
+      if (!(s.detJ > 0.0) && DOK) {                     // rare: count it from its lowest-numbered node only
+        const int *gn = A.vnode + d.node_off;
+        const int g0 = gn[n0];
+        if (g0 < gn[n1] && g0 < gn[n2] && g0 < gn[n3]) atomicAdd(A.bad, 1);
+      }
+      if (s.detJ != 0.0) {                               // fea_solver.c:697: no gradient otherwise
+        const double ga[3] = {s.g[0][0], s.g[0][1], s.g[0][2]};
+        if (DOF && !(A.dbg & 2)) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const double v = -s.vol * (s.sig[i][0] * ga[0] + s.sig[i][1] * ga[1] + s.sig[i][2] * ga[2]);
+            __hip_atomic_fetch_add(sF + n0 * 3 + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+        if (DOK) {
+          const int rowoff = sRow[n0] * 9;               // row node first: n0 is the row, chunk-local
+#pragma unroll
+          for (int k = 1; k < 4; ++k) {                  // the diagonal block comes from the row sum
+            double h[3], m[3], t[3], blk[9];
+            col_vectors(s.g[k], s.sig, s.l1, s.m1, s.vol, h, m, t);
+            block_ab(ga, h, m, t, blk);
+            double *dst = sK + rowoff + (int)((sl >> (8 * k)) & 255u) * 9;
+            if (A.dbg & 1) dst = sK + lane * 9;
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+              __hip_atomic_fetch_add(dst + q, blk[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
+    rec = nxt;
+  }
+  __syncthreads();
+
+  if (DOK) {
+    // K_aa = -sum_{b != a} K_ab (shape functions sum to one)
+    for (int t = lane; t < nrows * 9; t += 64) {
+      const int r = t / 9, q = t % 9;
+      const int kb = sRow[r], ke = sRow[r + 1], kd = sDiag[r];
+      double a = 0;
+      for (int k = kb; k < ke; ++k) a += (k == kd) ? 0.0 : sK[k * 9 + q];
+      sK[kd * 9 + q] = -a;
+    }
+    __syncthreads();
+    double *Kd = A.K + (size_t)d.b0 * 9;
+    for (int t = lane; t < d.nb * 9; t += 64) Kd[t] = sK[t];
+  }
+  if (DOF) {
+    double *fd = A.f + (size_t)d.r0 * 3;
+    for (int t = lane; t < nrows * 3; t += 64) fd[t] = sF[t];
+  }
+}
+
+int launch_assemble_visit(feahip_ctx *c, bool doK, bool doF)
+{
+  VisitArgs A;
+  A.chunk0 = c->chunk0; A.nchunks = c->nchunks_local; A.model = c->model;
+  A.lambda = c->lambda; A.mu = c->mu; A.tab = c->d_table; A.desc = c->d_vdesc; A.vnode = c->d_vnode;
+  A.vrec = reinterpret_cast<const uint2 *>(c->d_vrec); A.X0 = c->d_X0; A.x = c->d_x;
+  A.rowptr = c->d_rowptr; A.diag = c->d_diag; A.K = c->d_K; A.f = c->d_f; A.bad = c->d_flag + 1;
+  { const char *e = getenv("FEAHIP_DBG"); A.dbg = e ? atoi(e) : 0; }
+  if (c->nchunks_local <= 0) return FEAHIP_OK;
+  const dim3 grid(c->nchunks_local), blk(64);
+  if (doK && doF) hipLaunchKernelGGL((k_assemble_visit<true, true>), grid, blk, 0, c->stream, A);
+  else if (doK)   hipLaunchKernelGGL((k_assemble_visit<true, false>), grid, blk, 0, c->stream, A);
+  else            hipLaunchKernelGGL((k_assemble_visit<false, true>), grid, blk, 0, c->stream, A);
+  FEA_HIP_CHECK(c, hipGetLastError());
+  return FEAHIP_OK;
+}

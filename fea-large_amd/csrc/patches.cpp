@@ -131,3 +131,73 @@ void build_host_patches(int N, int E, const int *conn, const HostPattern &hp, Ho
     }
   });
 }
+
+// ---------------------------------------------------------------------------
+// visit records for kernels_visit.hip
+// ---------------------------------------------------------------------------
+void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, HostVisits &out)
+{
+  (void)N;
+  const int np = (int)hp.chunk.size() - 1;
+  out.ok = true;
+  out.desc.resize((size_t)np);
+  out.vrec.assign((size_t)E * 4 * 2, 0);
+  std::vector<std::vector<int>> nodes((size_t)np);
+  std::vector<char> bad((size_t)np, 0);
+  par_for(np, [&](int lo, int hi) {
+    std::vector<int> halo;
+    for (int p = lo; p < hi; ++p) {
+      const int r0 = hp.chunk[p], r1 = hp.chunk[p + 1];
+      const int p0 = hp.incptr[r0], p1 = hp.incptr[r1];
+      // owned rows first (chunk-local id = row - r0), then the other nodes ascending
+      halo.clear();
+      for (int q = p0; q < p1; ++q) {
+        const int e = (int)(hp.inc[q] & 0x0FFFFFFFu);
+        for (int k = 0; k < 4; ++k) {
+          const int g = conn[(size_t)e * 4 + k];
+          if (g < r0 || g >= r1) halo.push_back(g);
+        }
+      }
+      std::sort(halo.begin(), halo.end());
+      halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
+      std::vector<int> &nd = nodes[p];
+      nd.clear();
+      for (int r = r0; r < r1; ++r) nd.push_back(r);
+      nd.insert(nd.end(), halo.begin(), halo.end());
+      const int nown = r1 - r0;
+      if ((int)nd.size() > FEA_VISIT_MAX_NODES || p1 - p0 > 64 * FEA_VISIT_MAX_ROUNDS ||
+          hp.rowptr[r1] - hp.rowptr[r0] > FEA_CHUNK_BLOCKS || hp.incslot.empty()) { bad[p] = 1; continue; }
+      auto lid = [&](int g) {
+        if (g >= r0 && g < r1) return g - r0;
+        return nown + (int)(std::lower_bound(halo.begin(), halo.end(), g) - halo.begin());
+      };
+      for (int q = p0; q < p1; ++q) {
+        const int e = (int)(hp.inc[q] & 0x0FFFFFFFu), la = (int)(hp.inc[q] >> 28);
+        uint32_t ids = 0, sl = 0;
+        for (int k = 0; k < 4; ++k) {
+          ids |= (uint32_t)lid(conn[(size_t)e * 4 + (k ^ la)]) << (8 * k);   // row node first
+          if (k) sl |= (uint32_t)hp.incslot[(size_t)q * 4 + k] << (8 * k);
+        }
+        out.vrec[(size_t)q * 2] = ids;
+        out.vrec[(size_t)q * 2 + 1] = sl;
+      }
+    }
+  });
+  size_t no = 0;
+  for (int p = 0; p < np; ++p) {
+    if (bad[p]) { out.ok = false; break; }
+    VisitDesc &d = out.desc[p];
+    d.r0 = hp.chunk[p]; d.r1 = hp.chunk[p + 1];
+    d.b0 = hp.rowptr[d.r0]; d.nb = hp.rowptr[d.r1] - d.b0;
+    d.node_off = (int)no; d.nnode = (int)nodes[p].size();
+    d.visit_off = hp.incptr[d.r0]; d.nvisit = hp.incptr[d.r1] - d.visit_off;
+    no += nodes[p].size();
+    if (no > 0x7FFFFFFFull) { out.ok = false; break; }
+  }
+  if (!out.ok) { out.desc.clear(); out.vrec.clear(); return; }
+  out.vnode.resize(no);
+  par_for(np, [&](int lo, int hi) {
+    for (int p = lo; p < hi; ++p)
+      std::copy(nodes[p].begin(), nodes[p].end(), out.vnode.begin() + out.desc[p].node_off);
+  });
+}

@@ -46,9 +46,11 @@ enum {
   FEAHIP_ASM_ROWOWNER = 1, /* node-centric gather, every CSR value written
                               once, deterministic                            */
   FEAHIP_ASM_ATOMIC = 2,   /* element-parallel, FP64 atomics into the CSR    */
-  FEAHIP_ASM_PATCH = 3     /* linear tets: element states shared through LDS,
+  FEAHIP_ASM_PATCH = 3,    /* linear tets: element states shared through LDS,
                               block owners gather; no atomics, bitwise
                               reproducible                                   */
+  FEAHIP_ASM_STAGED = 4    /* linear tets: row-owner visits with node
+                              coordinates and connectivity staged in LDS     */
 };
 
 /* ---- lifetime ----------------------------------------------------------- */
