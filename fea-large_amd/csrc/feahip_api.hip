@@ -74,6 +74,9 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
   c->max_rowlen = hp.max_rowlen;
   c->nchunks = (int)hp.chunk.size() - 1;
   c->chunk0 = 0; c->nchunks_local = c->nchunks;
+  c->nachunks = hp.achunk.empty() ? 0 : (int)hp.achunk.size() - 1;
+  c->achunk0 = 0; c->nachunks_local = c->nachunks;
+  c->h_super_achunk = hp.super_achunk;
   c->h_rowptr = hp.rowptr; c->h_colidx = hp.colidx;
 
   if ((rc = dev_upload(c, &c->d_conn, elements, (size_t)n_elems * npe))) return rc;
@@ -215,9 +218,16 @@ extern "C" int feahip_set_row_shard(feahip_ctx *c, int rank, int nranks)
 {
   CTX_GUARD(c);
   if (nranks < 1 || rank < 0 || rank >= nranks) { c->err = "bad shard (rank, nranks)"; return FEAHIP_EINVAL; }
-  // equal numbers of chunks = near-equal numbers of 3x3 blocks per rank
-  c->chunk0 = (int)((long long)c->nchunks * rank / nranks);
-  c->nchunks_local = (int)((long long)c->nchunks * (rank + 1) / nranks) - c->chunk0;
+  // shards are ranges of "supers" (FEA_SUPER_CHUNKS SpMV chunks each): equal
+  // numbers of supers = near-equal numbers of 3x3 blocks per rank
+  const int nsuper = (c->nchunks + FEA_SUPER_CHUNKS - 1) / FEA_SUPER_CHUNKS;
+  const int s0 = (int)((long long)nsuper * rank / nranks), s1 = (int)((long long)nsuper * (rank + 1) / nranks);
+  c->chunk0 = s0 * FEA_SUPER_CHUNKS;
+  c->nchunks_local = (s1 * FEA_SUPER_CHUNKS < c->nchunks ? s1 * FEA_SUPER_CHUNKS : c->nchunks) - c->chunk0;
+  if (!c->h_super_achunk.empty()) {
+    c->achunk0 = c->h_super_achunk[s0];
+    c->nachunks_local = c->h_super_achunk[s1] - c->achunk0;
+  }
   return FEAHIP_OK;
 }
 

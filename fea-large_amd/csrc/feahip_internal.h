@@ -36,6 +36,8 @@ struct feahip_ctx {
   int nnzb = 0;               // 3x3 blocks in the full symmetric pattern
   int nchunks = 0;
   int chunk0 = 0, nchunks_local = 0;  // this rank's share of the chunks (row shard)
+  int nachunks = 0, achunk0 = 0, nachunks_local = 0;   // same for the staged kernel's partition
+  std::vector<int> h_super_achunk;
   int max_rowlen = 0;
   bool linear_tet = false;    // npe == 4 and dN is the constant-strain table
   int model = 0;
@@ -113,6 +115,9 @@ struct HostPattern {
   std::vector<uint8_t> incslot;          // [npe*E*npe]
   std::vector<int> chunk;                // chunk -> first row
   std::vector<int> diag;                 // row -> index of its diagonal block
+  std::vector<uint32_t> inc_rows;        // inc before the per-chunk interleave (row-sorted)
+  std::vector<int> achunk;               // assembly partition of the staged kernel (4-node elements)
+  std::vector<int> super_achunk;         // first achunk of every super, [nsuper+1]
   int max_rowlen = 0;
 };
 int build_host_pattern(int N, int E, int npe, const int *conn, HostPattern &hp,
@@ -143,8 +148,12 @@ void build_host_patches(int N, int E, const int *conn, const HostPattern &hp, Ho
 // LDS-staged visit assembly (kernels_visit.hip): per chunk, the nodes its
 // elements touch (owned rows first) and one 8-byte record per (row, element)
 // visit: 4 chunk-local node ids (row node first) + 3 column slots.
-#define FEA_VISIT_MAX_NODES 128
-#define FEA_VISIT_MAX_ROUNDS 6
+// assembly chunks of the staged kernel are smaller than the SpMV chunks (LDS
+// per wave sets the occupancy): two passes of 64 visits, 64 nodes, 80 blocks
+#define FEA_VISIT_MAX_NODES 64
+#define FEA_VISIT_MAX_VISITS 128
+#define FEA_ACHUNK_BLOCKS 80
+#define FEA_SUPER_CHUNKS 8            // a "super" = 8 SpMV chunks; both partitions break at supers; unit of the row shard
 struct VisitDesc {                   // 32 bytes, one per chunk
   int r0, r1, b0, nb;
   int node_off, nnode;               // into vnode

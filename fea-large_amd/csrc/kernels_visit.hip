@@ -30,7 +30,8 @@ struct VisitArgs {
   const int *rowptr, *diag;
   double *K, *f;
   int *bad;
-  int dbg;                       // timing experiments only (FEAHIP_DBG): 1 = conflict-free K adds, 2 = no f adds
+  int dbg;                       // timing experiments only (FEAHIP_DBG): 1 = conflict-free K adds, 2 = no f adds, 4 = phase stamps
+  unsigned long long *stamps;    // [chunk][8] s_memtime stamps when dbg & 4
 };
 
 template <bool DOK, bool DOF>
@@ -38,32 +39,43 @@ __global__ __launch_bounds__(64)
 void k_assemble_visit(VisitArgs A)
 {
   __shared__ double sC[FEA_VISIT_MAX_NODES * 6];       // x, X0 of the chunk's nodes
-  __shared__ double sK[DOK ? FEA_CHUNK_BLOCKS * 9 : 1];
+  __shared__ double sK[DOK ? FEA_ACHUNK_BLOCKS * 9 + 2 : 2];
   __shared__ double sF[FEA_CHUNK_ROWS * 3];
   __shared__ int sRow[FEA_CHUNK_ROWS + 1];             // first block of every row, relative to b0
   __shared__ int sDiag[FEA_CHUNK_ROWS];
   const int lane = threadIdx.x;
-  const VisitDesc d = A.desc[A.chunk0 + blockIdx.x];
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+  if (A.dbg & 4) t0 = __builtin_amdgcn_s_memtime();
+  // node lists have a fixed stride per chunk, so they are fetched together with
+  // the descriptor (one dependent latency less); unused tail entries are 0
+  const int chunk = A.chunk0 + blockIdx.x;
+  const int vn0 = A.vnode[(size_t)chunk * FEA_VISIT_MAX_NODES + lane];
+  const VisitDesc d = A.desc[chunk];
   const int nrows = d.r1 - d.r0;
+  // the tile sits at an LDS offset with the parity of the chunk's first global
+  // value, so LDS and HBM agree on 16-byte alignment in the write-out
+  const int odd = d.b0 & 1;
+  double *sKt = sK + odd;
 
   uint2 rec = make_uint2(0, 0);
   if (lane < d.nvisit) rec = A.vrec[d.visit_off + lane];
   if (lane <= nrows) sRow[lane] = A.rowptr[d.r0 + lane] - d.b0;
   if (lane < nrows) sDiag[lane] = A.diag[d.r0 + lane] - d.b0;
-  for (int i = lane; i < d.nnode; i += 64) {
-    const size_t n = (size_t)A.vnode[d.node_off + i];
+  if (lane < d.nnode) {
+    const size_t n = (size_t)vn0;
     const double2 a0 = *reinterpret_cast<const double2 *>(A.x + n * 4);
     const double2 a1 = *reinterpret_cast<const double2 *>(A.x + n * 4 + 2);
     const double2 c0 = *reinterpret_cast<const double2 *>(A.X0 + n * 4);
     const double2 c1 = *reinterpret_cast<const double2 *>(A.X0 + n * 4 + 2);
-    double *o = sC + i * 6;
+    double *o = sC + lane * 6;
     o[0] = a0.x; o[1] = a0.y; o[2] = a1.x; o[3] = c0.x; o[4] = c0.y; o[5] = c1.x;
   }
   if (DOK)
-    for (int t = lane; t < d.nb * 9; t += 64) sK[t] = 0.0;
+    for (int t = lane; t < d.nb * 9; t += 64) sKt[t] = 0.0;
   if (DOF)
     for (int t = lane; t < nrows * 3; t += 64) sF[t] = 0.0;
   __syncthreads();
+  if (A.dbg & 4) t1 = __builtin_amdgcn_s_memtime();
 
   for (int p = lane; p - lane < d.nvisit; p += 64) {
     // record of the next pass, in flight while this one computes
@@ -83,7 +95,7 @@ void k_assemble_visit(VisitArgs A)
       GPState<4> s;
       gp_state<4, true, false>(xe, Xe, A.tab, 0, A.model, A.lambda, A.mu, s);
       if (!(s.detJ > 0.0) && DOK) {                     // rare: count it from its lowest-numbered node only
-        const int *gn = A.vnode + d.node_off;
+        const int *gn = A.vnode + (size_t)chunk * FEA_VISIT_MAX_NODES;
         const int g0 = gn[n0];
         if (g0 < gn[n1] && g0 < gn[n2] && g0 < gn[n3]) atomicAdd(A.bad, 1);
       }
@@ -103,8 +115,8 @@ void k_assemble_visit(VisitArgs A)
             double h[3], m[3], t[3], blk[9];
             col_vectors(s.g[k], s.sig, s.l1, s.m1, s.vol, h, m, t);
             block_ab(ga, h, m, t, blk);
-            double *dst = sK + rowoff + (int)((sl >> (8 * k)) & 255u) * 9;
-            if (A.dbg & 1) dst = sK + lane * 9;
+            double *dst = sKt + rowoff + (int)((sl >> (8 * k)) & 255u) * 9;
+            if (A.dbg & 1) dst = sKt + lane * 9;
 #pragma unroll
             for (int q = 0; q < 9; ++q)
               __hip_atomic_fetch_add(dst + q, blk[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -115,39 +127,84 @@ void k_assemble_visit(VisitArgs A)
     rec = nxt;
   }
   __syncthreads();
+  if (A.dbg & 4) t2 = __builtin_amdgcn_s_memtime();
 
   if (DOK) {
-    // K_aa = -sum_{b != a} K_ab (shape functions sum to one)
+    // K_aa = -sum_{b != a} K_ab (shape functions sum to one).  The diagonal
+    // block was never added to (still zero), so the whole row is summed;
+    // four independent partial sums keep the LDS reads pipelined.
     for (int t = lane; t < nrows * 9; t += 64) {
       const int r = t / 9, q = t % 9;
       const int kb = sRow[r], ke = sRow[r + 1], kd = sDiag[r];
-      double a = 0;
-      for (int k = kb; k < ke; ++k) a += (k == kd) ? 0.0 : sK[k * 9 + q];
-      sK[kd * 9 + q] = -a;
+      double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+      int k = kb;
+      for (; k + 3 < ke; k += 4) {
+        a0 += sKt[k * 9 + q]; a1 += sKt[(k + 1) * 9 + q]; a2 += sKt[(k + 2) * 9 + q]; a3 += sKt[(k + 3) * 9 + q];
+      }
+      for (; k < ke; ++k) a0 += sKt[k * 9 + q];
+      sKt[kd * 9 + q] = -((a0 + a1) + (a2 + a3));
     }
     __syncthreads();
+    if (A.dbg & 4) t3 = __builtin_amdgcn_s_memtime();
+    // stream the finished rows out: 16-byte LDS reads and HBM stores
     double *Kd = A.K + (size_t)d.b0 * 9;
-    for (int t = lane; t < d.nb * 9; t += 64) Kd[t] = sK[t];
+    const int total = d.nb * 9;
+    if (odd && lane == 0) Kd[0] = sKt[0];
+    const int npair = (total - odd) >> 1;
+    for (int t = lane; t < npair; t += 64) {
+      const int j = odd + 2 * t;
+      *reinterpret_cast<double2 *>(Kd + j) = *reinterpret_cast<const double2 *>(sKt + j);
+    }
+    if (((total - odd) & 1) && lane == 0) Kd[total - 1] = sKt[total - 1];
   }
   if (DOF) {
     double *fd = A.f + (size_t)d.r0 * 3;
     for (int t = lane; t < nrows * 3; t += 64) fd[t] = sF[t];
+  }
+  if (A.dbg & 4) {
+    __builtin_amdgcn_s_waitcnt(0);
+    t4 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+      unsigned long long *o = A.stamps + (size_t)blockIdx.x * 8;
+      o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t4 - t3; o[4] = t4 - t0; o[5] = t0; o[6] = t4; o[7] = t5;
+    }
   }
 }
 
 int launch_assemble_visit(feahip_ctx *c, bool doK, bool doF)
 {
   VisitArgs A;
-  A.chunk0 = c->chunk0; A.nchunks = c->nchunks_local; A.model = c->model;
+  A.chunk0 = c->achunk0; A.nchunks = c->nachunks_local; A.model = c->model;
   A.lambda = c->lambda; A.mu = c->mu; A.tab = c->d_table; A.desc = c->d_vdesc; A.vnode = c->d_vnode;
   A.vrec = reinterpret_cast<const uint2 *>(c->d_vrec); A.X0 = c->d_X0; A.x = c->d_x;
   A.rowptr = c->d_rowptr; A.diag = c->d_diag; A.K = c->d_K; A.f = c->d_f; A.bad = c->d_flag + 1;
   { const char *e = getenv("FEAHIP_DBG"); A.dbg = e ? atoi(e) : 0; }
-  if (c->nchunks_local <= 0) return FEAHIP_OK;
-  const dim3 grid(c->nchunks_local), blk(64);
+  static unsigned long long *d_stamps = nullptr;
+  if ((A.dbg & 4) && !d_stamps) (void)hipMalloc((void **)&d_stamps, sizeof(unsigned long long) * 8 * (size_t)c->nachunks);
+  A.stamps = d_stamps;
+  if (c->nachunks_local <= 0) return FEAHIP_OK;
+  const dim3 grid(c->nachunks_local), blk(64);
   if (doK && doF) hipLaunchKernelGGL((k_assemble_visit<true, true>), grid, blk, 0, c->stream, A);
   else if (doK)   hipLaunchKernelGGL((k_assemble_visit<true, false>), grid, blk, 0, c->stream, A);
   else            hipLaunchKernelGGL((k_assemble_visit<false, true>), grid, blk, 0, c->stream, A);
   FEA_HIP_CHECK(c, hipGetLastError());
+  if (A.dbg & 4) {                                  // diagnostic build path: phase shares, never a timing
+    static int printed = 0;
+    (void)hipStreamSynchronize(c->stream);
+    if (printed++ == 3) {
+      std::vector<unsigned long long> h((size_t)c->nachunks_local * 8);
+      (void)hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost);
+      double sum[5] = {0, 0, 0, 0, 0};
+      unsigned long long tmin = ~0ull, tmax = 0;
+      for (int i = 0; i < c->nachunks_local; ++i) {
+        for (int k = 0; k < 5; ++k) sum[k] += (double)h[(size_t)i * 8 + k];
+        if (h[(size_t)i * 8 + 5] < tmin) tmin = h[(size_t)i * 8 + 5];
+        if (h[(size_t)i * 8 + 6] > tmax) tmax = h[(size_t)i * 8 + 6];
+      }
+      fprintf(stderr, "[feahip stamps] K=%d F=%d chunks=%d  mean cycles: setup %.0f  rounds %.0f  diag %.0f  writeout %.0f  total %.0f  | kernel span %llu ticks\n",
+              (int)doK, (int)doF, c->nachunks_local, sum[0] / c->nachunks_local, sum[1] / c->nachunks_local,
+              sum[2] / c->nachunks_local, sum[3] / c->nachunks_local, sum[4] / c->nachunks_local, tmax - tmin);
+    }
+  }
   return FEAHIP_OK;
 }

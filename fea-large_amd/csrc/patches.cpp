@@ -138,21 +138,27 @@ void build_host_patches(int N, int E, const int *conn, const HostPattern &hp, Ho
 void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, HostVisits &out)
 {
   (void)N;
-  const int np = (int)hp.chunk.size() - 1;
-  out.ok = true;
+  out.ok = false;
+  if (hp.achunk.size() < 2) return;
+  const int np = (int)hp.achunk.size() - 1;
   out.desc.resize((size_t)np);
   out.vrec.assign((size_t)E * 4 * 2, 0);
-  std::vector<std::vector<int>> nodes((size_t)np);
+  out.vnode.assign((size_t)np * FEA_VISIT_MAX_NODES, 0);
   std::vector<char> bad((size_t)np, 0);
   par_for(np, [&](int lo, int hi) {
     std::vector<int> halo;
+    std::vector<uint32_t> vis;
     for (int p = lo; p < hi; ++p) {
-      const int r0 = hp.chunk[p], r1 = hp.chunk[p + 1];
+      const int r0 = hp.achunk[p], r1 = hp.achunk[p + 1];
       const int p0 = hp.incptr[r0], p1 = hp.incptr[r1];
+      const int b0 = hp.rowptr[r0];
+      VisitDesc &d = out.desc[p];
+      d.r0 = r0; d.r1 = r1; d.b0 = b0; d.nb = hp.rowptr[r1] - b0;
+      d.node_off = p * FEA_VISIT_MAX_NODES; d.visit_off = p0; d.nvisit = p1 - p0;
       // owned rows first (chunk-local id = row - r0), then the other nodes ascending
       halo.clear();
       for (int q = p0; q < p1; ++q) {
-        const int e = (int)(hp.inc[q] & 0x0FFFFFFFu);
+        const int e = (int)(hp.inc_rows[q] & 0x0FFFFFFFu);
         for (int k = 0; k < 4; ++k) {
           const int g = conn[(size_t)e * 4 + k];
           if (g < r0 || g >= r1) halo.push_back(g);
@@ -160,44 +166,42 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
       }
       std::sort(halo.begin(), halo.end());
       halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
-      std::vector<int> &nd = nodes[p];
-      nd.clear();
-      for (int r = r0; r < r1; ++r) nd.push_back(r);
-      nd.insert(nd.end(), halo.begin(), halo.end());
       const int nown = r1 - r0;
-      if ((int)nd.size() > FEA_VISIT_MAX_NODES || p1 - p0 > 64 * FEA_VISIT_MAX_ROUNDS ||
-          hp.rowptr[r1] - hp.rowptr[r0] > FEA_CHUNK_BLOCKS || hp.incslot.empty()) { bad[p] = 1; continue; }
+      d.nnode = nown + (int)halo.size();
+      if (d.nnode > FEA_VISIT_MAX_NODES || d.nvisit > FEA_VISIT_MAX_VISITS || d.nb > FEA_ACHUNK_BLOCKS ||
+          nown > FEA_CHUNK_ROWS) { bad[p] = 1; continue; }
+      int *vn = out.vnode.data() + (size_t)p * FEA_VISIT_MAX_NODES;
+      for (int r = r0; r < r1; ++r) vn[r - r0] = r;
+      std::copy(halo.begin(), halo.end(), vn + nown);
       auto lid = [&](int g) {
         if (g >= r0 && g < r1) return g - r0;
         return nown + (int)(std::lower_bound(halo.begin(), halo.end(), g) - halo.begin());
       };
-      for (int q = p0; q < p1; ++q) {
-        const int e = (int)(hp.inc[q] & 0x0FFFFFFFu), la = (int)(hp.inc[q] >> 28);
+      // visits dealt round-robin over the rows: the lanes of one pass then work
+      // on as many different rows as the chunk has (few same-address LDS adds)
+      vis.clear();
+      int maxlen = 0;
+      for (int r = r0; r < r1; ++r) maxlen = std::max(maxlen, hp.incptr[r + 1] - hp.incptr[r]);
+      for (int k = 0; k < maxlen; ++k)
+        for (int r = r0; r < r1; ++r)
+          if (k < hp.incptr[r + 1] - hp.incptr[r]) vis.push_back(hp.inc_rows[hp.incptr[r] + k]);
+      for (int v = 0; v < (int)vis.size(); ++v) {
+        const int e = (int)(vis[v] & 0x0FFFFFFFu), la = (int)(vis[v] >> 28);
+        const int a = conn[(size_t)e * 4 + la];
+        const int *cb = hp.colidx.data() + hp.rowptr[a], *ce = hp.colidx.data() + hp.rowptr[a + 1];
         uint32_t ids = 0, sl = 0;
         for (int k = 0; k < 4; ++k) {
-          ids |= (uint32_t)lid(conn[(size_t)e * 4 + (k ^ la)]) << (8 * k);   // row node first
-          if (k) sl |= (uint32_t)hp.incslot[(size_t)q * 4 + k] << (8 * k);
+          const int g = conn[(size_t)e * 4 + (k ^ la)];                 // row node first
+          ids |= (uint32_t)lid(g) << (8 * k);
+          if (k) sl |= (uint32_t)(std::lower_bound(cb, ce, g) - cb) << (8 * k);
         }
-        out.vrec[(size_t)q * 2] = ids;
-        out.vrec[(size_t)q * 2 + 1] = sl;
+        out.vrec[(size_t)(p0 + v) * 2] = ids;
+        out.vrec[(size_t)(p0 + v) * 2 + 1] = sl;
       }
     }
   });
-  size_t no = 0;
-  for (int p = 0; p < np; ++p) {
-    if (bad[p]) { out.ok = false; break; }
-    VisitDesc &d = out.desc[p];
-    d.r0 = hp.chunk[p]; d.r1 = hp.chunk[p + 1];
-    d.b0 = hp.rowptr[d.r0]; d.nb = hp.rowptr[d.r1] - d.b0;
-    d.node_off = (int)no; d.nnode = (int)nodes[p].size();
-    d.visit_off = hp.incptr[d.r0]; d.nvisit = hp.incptr[d.r1] - d.visit_off;
-    no += nodes[p].size();
-    if (no > 0x7FFFFFFFull) { out.ok = false; break; }
-  }
-  if (!out.ok) { out.desc.clear(); out.vrec.clear(); return; }
-  out.vnode.resize(no);
-  par_for(np, [&](int lo, int hi) {
-    for (int p = lo; p < hi; ++p)
-      std::copy(nodes[p].begin(), nodes[p].end(), out.vnode.begin() + out.desc[p].node_off);
-  });
+  for (int p = 0; p < np; ++p)
+    if (bad[p]) { out.desc.clear(); out.vrec.clear(); out.vnode.clear(); return; }
+  if (hp.max_rowlen > 255) { out.desc.clear(); out.vrec.clear(); out.vnode.clear(); return; }
+  out.ok = true;
 }

@@ -114,6 +114,49 @@ int build_host_pattern(int N, int E, int npe, const int *conn, HostPattern &hp,
     }
   });
 
+  // Assembly partition of the staged kernel: finer chunks (visits, nodes and
+  // blocks bounded so a wave's LDS footprint stays ~10 KB), nested in supers of
+  // FEA_SUPER_CHUNKS SpMV chunks so both partitions share the shard boundaries.
+  hp.inc_rows = hp.inc;
+  hp.achunk.clear(); hp.super_achunk.clear();
+  if (npe == 4) {
+    std::vector<int> stamp((size_t)N, -1);
+    int serial = 0;
+    for (int s0 = 0; s0 < nchunks; s0 += FEA_SUPER_CHUNKS) {
+      const int s1 = std::min(nchunks, s0 + FEA_SUPER_CHUNKS);
+      hp.super_achunk.push_back((int)hp.achunk.size());
+      const int ra = hp.chunk[s0], rb = hp.chunk[s1];
+      int r0 = ra;
+      while (r0 < rb) {
+        int r = r0, nblk = 0, nvis = 0, nnod = 0;
+        ++serial;
+        for (; r < rb && r - r0 < FEA_CHUNK_ROWS; ++r) {
+          const int len = hp.rowptr[r + 1] - hp.rowptr[r], vis = hp.incptr[r + 1] - hp.incptr[r];
+          // nodes this row would add
+          int add = 0;
+          std::vector<int> fresh;
+          for (int q = hp.incptr[r]; q < hp.incptr[r + 1]; ++q) {
+            const int e = (int)(hp.inc_rows[q] & 0x0FFFFFFFu);
+            for (int k = 0; k < 4; ++k) {
+              const int g = conn[(size_t)e * 4 + k];
+              if (stamp[g] != serial) { stamp[g] = serial; fresh.push_back(g); ++add; }
+            }
+          }
+          if (r > r0 && (nblk + len > FEA_ACHUNK_BLOCKS || nvis + vis > FEA_VISIT_MAX_VISITS ||
+                         nnod + add > FEA_VISIT_MAX_NODES)) {
+            for (int g : fresh) stamp[g] = -1;     // not taken
+            break;
+          }
+          nblk += len; nvis += vis; nnod += add;
+        }
+        hp.achunk.push_back(r0);
+        r0 = r;
+      }
+    }
+    hp.super_achunk.push_back((int)hp.achunk.size());
+    hp.achunk.push_back(N);
+  }
+
   // Inside a chunk the (row, element) visits are dealt round-robin over the
   // rows: the 64 lanes of one pass then work on as many different rows as the
   // chunk has, which keeps LDS adds to one address few (same-address

@@ -18,7 +18,9 @@ PASSES=(
  "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"
 )
 i=0
+NP=${PMC_PASSES:-99}
 for P in "${PASSES[@]}"; do
+  [ $i -ge $NP ] && break
   i=$((i+1))
   timeout -k 10 240 rocprofv3 --pmc $P --output-format csv -d "$OUT/pass$i" -- python3 "$ROOTDIR/bench.py" --no-newton --cpu-sample 0 --steps 3 --warmup 1 "$@" > "$OUT/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$OUT/pass$i.log"; exit 1; }
   echo "pass $i done"
