@@ -1,0 +1,145 @@
+// dist.hip -- row-sharded (multi-GPU) operation: shard installation, the RCCL
+// transport, the Newton loop over one or more ranks.
+//
+// Production shape (bench.py, torch.distributed launch): one process per GPU,
+// one context per process, halo rows over ncclSend/ncclRecv (point-to-point
+// over xGMI; every rank talks to its slab neighbours only) and one to three
+// doubles per ncclAllReduce.  No vector all-reduce, no all-gather on the path.
+// The same loop also drives an in-process group of contexts (GroupTransport),
+// which is how the sharded path is exercised where one process sees the GPU.
+#include "feahip_internal.h"
+#include <rccl/rccl.h>
+#include <cmath>
+#include <cstring>
+
+int install_shard(feahip_ctx *c, int rank, int nranks)
+{
+  if (nranks < 1 || rank < 0 || rank >= nranks) { c->err = "bad shard (rank, nranks)"; return FEAHIP_EINVAL; }
+  const int nsuper = (c->nchunks + FEA_SUPER_CHUNKS - 1) / FEA_SUPER_CHUNKS;
+  const int s0 = (int)((long long)nsuper * rank / nranks), s1 = (int)((long long)nsuper * (rank + 1) / nranks);
+  c->chunk0 = s0 * FEA_SUPER_CHUNKS < c->nchunks ? s0 * FEA_SUPER_CHUNKS : c->nchunks;
+  c->nchunks_local = (s1 * FEA_SUPER_CHUNKS < c->nchunks ? s1 * FEA_SUPER_CHUNKS : c->nchunks) - c->chunk0;
+  if (!c->h_super_achunk.empty()) {
+    c->achunk0 = c->h_super_achunk[s0];
+    c->nachunks_local = c->h_super_achunk[s1] - c->achunk0;
+  }
+  ShardPlan plan;
+  build_shard_plan(c->h_rowptr, c->h_colidx, c->h_chunk, rank, nranks, plan);
+  c->rank = rank; c->nranks = nranks; c->row0 = plan.row0; c->row1 = plan.row1;
+  c->peer = plan.peer; c->send_off = plan.send_off; c->recv_off = plan.recv_off;
+  c->nsend = (int)plan.send_idx.size(); c->nrecv = (int)plan.recv_idx.size();
+  for (void *p : {(void *)c->d_send_idx, (void *)c->d_recv_idx, (void *)c->d_send_buf, (void *)c->d_recv_buf})
+    if (p) (void)hipFree(p);
+  c->d_send_idx = c->d_recv_idx = nullptr; c->d_send_buf = c->d_recv_buf = nullptr;
+  auto up = [&](int **dst, const std::vector<int> &v) -> int {
+    FEA_HIP_CHECK(c, hipMalloc((void **)dst, sizeof(int) * (v.size() ? v.size() : 1)));
+    if (!v.empty()) FEA_HIP_CHECK(c, hipMemcpy(*dst, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice));
+    return FEAHIP_OK;
+  };
+  int rc;
+  if ((rc = up(&c->d_send_idx, plan.send_idx))) return rc;
+  if ((rc = up(&c->d_recv_idx, plan.recv_idx))) return rc;
+  FEA_HIP_CHECK(c, hipMalloc((void **)&c->d_send_buf, sizeof(double) * 3 * (size_t)(c->nsend ? c->nsend : 1)));
+  FEA_HIP_CHECK(c, hipMalloc((void **)&c->d_recv_buf, sizeof(double) * 3 * (size_t)(c->nrecv ? c->nrecv : 1)));
+  return FEAHIP_OK;
+}
+
+// ---- RCCL ------------------------------------------------------------------
+struct RcclTransport : Transport {
+  ncclComm_t comm = nullptr;
+  ~RcclTransport() override { if (comm) (void)ncclCommDestroy(comm); }
+  int fail(feahip_ctx *c, const char *what, ncclResult_t r)
+  {
+    c->err = std::string(what) + ": " + ncclGetErrorString(r);
+    return FEAHIP_ECOMM;
+  }
+  int exchange(std::vector<feahip_ctx *> &R, int which) override
+  {
+    feahip_ctx *c = R[0];
+    int stride = (which == 2) ? 4 : 3;
+    double *v = which == 0 ? c->d_p : (which == 1 ? c->d_u : c->d_x);
+    extern void feahip_enq_pack(feahip_ctx *, double *, int);
+    extern void feahip_enq_unpack(feahip_ctx *, double *, int);
+    feahip_enq_pack(c, v, stride);
+    ncclResult_t r = ncclGroupStart();
+    if (r != ncclSuccess) return fail(c, "ncclGroupStart", r);
+    for (size_t k = 0; k < c->peer.size(); ++k) {
+      const size_t ns = (size_t)3 * (c->send_off[k + 1] - c->send_off[k]), nr = (size_t)3 * (c->recv_off[k + 1] - c->recv_off[k]);
+      if (ns && (r = ncclSend(c->d_send_buf + (size_t)3 * c->send_off[k], ns, ncclDouble, c->peer[k], comm, c->stream)) != ncclSuccess)
+        return fail(c, "ncclSend", r);
+      if (nr && (r = ncclRecv(c->d_recv_buf + (size_t)3 * c->recv_off[k], nr, ncclDouble, c->peer[k], comm, c->stream)) != ncclSuccess)
+        return fail(c, "ncclRecv", r);
+    }
+    if ((r = ncclGroupEnd()) != ncclSuccess) return fail(c, "ncclGroupEnd", r);
+    feahip_enq_unpack(c, v, stride);
+    return FEAHIP_OK;
+  }
+  int allreduce(std::vector<feahip_ctx *> &R, int slot, int n) override
+  {
+    feahip_ctx *c = R[0];
+    ncclResult_t r = ncclAllReduce(c->d_scal + 8 + slot, c->d_scal + 8 + slot, (size_t)n, ncclDouble, ncclSum, comm, c->stream);
+    if (r != ncclSuccess) return fail(c, "ncclAllReduce", r);
+    return FEAHIP_OK;
+  }
+};
+
+int rccl_unique_id(void *out, int cap)
+{
+  if (!out || cap < (int)sizeof(ncclUniqueId)) return FEAHIP_EINVAL;
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return FEAHIP_ECOMM;
+  memcpy(out, &id, sizeof(id));
+  return (int)sizeof(id);
+}
+
+Transport *make_rccl_transport(feahip_ctx *c, int rank, int nranks, const void *unique_id, std::string &err)
+{
+  ncclUniqueId id;
+  memcpy(&id, unique_id, sizeof(id));
+  RcclTransport *t = new RcclTransport();
+  (void)hipSetDevice(c->device);
+  ncclResult_t r = ncclCommInitRank(&t->comm, nranks, id, rank);
+  if (r != ncclSuccess) { err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); delete t; return nullptr; }
+  return t;
+}
+
+// ---- the loop of solve() over one or more ranks -------------------------------
+int dist_newton(std::vector<feahip_ctx *> &R, int load_increments, int max_newton, int modified_newton,
+                double desired_tolerance, int solver_type, double solver_tolerance, int solver_max_iter,
+                double *tol_log, int tol_log_cap, int *its_log, int *steps_done)
+{
+  int rc, nlog = 0, step = 0;
+#define EACH(call) for (feahip_ctx *c : R) { if ((rc = (call))) return rc; }
+  for (; step < load_increments; ++step) {                           // fea_solver.c:163
+    int it = 0;
+    double tolerance = 0;
+    EACH(feahip_update_nodes_with_bc(c, 1.0));                        // :168 (prescribed values are replicated)
+    EACH(feahip_update_state(c, nullptr));                            // :171-174
+    EACH(feahip_create_stiffness(c));                                 // :177 (owned rows, ghost elements recomputed)
+    if (modified_newton) EACH(feahip_stash_stiffness(c));             // :179
+    do {
+      it++;
+      if (modified_newton) {
+        EACH(feahip_create_residual_forces(c));                       // :185
+        EACH(feahip_restore_stiffness(c));                            // :194-195
+      } else if (it == 1) {
+        EACH(feahip_create_residual_forces(c));                       // K of :177 is current
+      } else {
+        EACH(feahip_create_stiffness_and_residual(c));                // :185 + :200
+      }
+      EACH(feahip_apply_prescribed_bc(c, 0.0));                       // :203
+      if ((rc = dist_solve_pcg(R, solver_type, solver_tolerance, solver_max_iter, nullptr, nullptr))) return rc;  // :205
+      if ((rc = dist_energy(R, &tolerance))) return rc;               // :208-210, identical on every rank
+      if (tol_log && nlog < tol_log_cap) tol_log[nlog] = tolerance;
+      nlog++;
+      if ((rc = dist_update_nodes_with_solution(R, nullptr))) return rc;   // :216
+      EACH(feahip_update_state(c, nullptr));                          // :217-218
+    } while (fabs(tolerance) > desired_tolerance && it < max_newton); // :220-221
+    if (its_log) its_log[step] = it;
+    if (it == max_newton) break;                                      // :225-231
+  }
+#undef EACH
+  if (steps_done) *steps_done = step;
+  for (feahip_ctx *c : R) { (void)hipSetDevice(c->device); FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream)); }
+  return FEAHIP_OK;
+}

@@ -1,5 +1,6 @@
 // feahip_api.hip -- extern "C" entry points of include/fea_hip.h.
 #include "feahip_internal.h"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -77,6 +78,8 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
   c->nachunks = hp.achunk.empty() ? 0 : (int)hp.achunk.size() - 1;
   c->achunk0 = 0; c->nachunks_local = c->nachunks;
   c->h_super_achunk = hp.super_achunk;
+  c->h_chunk = hp.chunk;
+  c->row0 = 0; c->row1 = n_nodes;
   c->h_rowptr = hp.rowptr; c->h_colidx = hp.colidx;
 
   if ((rc = dev_upload(c, &c->d_conn, elements, (size_t)n_elems * npe))) return rc;
@@ -191,6 +194,9 @@ extern "C" void feahip_destroy(feahip_ctx *c)
                   c->d_dofmask, c->d_F, c->d_S};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  for (void *p : {(void *)c->d_send_idx, (void *)c->d_recv_idx, (void *)c->d_send_buf, (void *)c->d_recv_buf})
+    if (p) (void)hipFree(p);
+  if (c->tr && c->owns_tr) delete c->tr;
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -217,18 +223,7 @@ extern "C" int feahip_set_assembly(feahip_ctx *c, int strategy)
 extern "C" int feahip_set_row_shard(feahip_ctx *c, int rank, int nranks)
 {
   CTX_GUARD(c);
-  if (nranks < 1 || rank < 0 || rank >= nranks) { c->err = "bad shard (rank, nranks)"; return FEAHIP_EINVAL; }
-  // shards are ranges of "supers" (FEA_SUPER_CHUNKS SpMV chunks each): equal
-  // numbers of supers = near-equal numbers of 3x3 blocks per rank
-  const int nsuper = (c->nchunks + FEA_SUPER_CHUNKS - 1) / FEA_SUPER_CHUNKS;
-  const int s0 = (int)((long long)nsuper * rank / nranks), s1 = (int)((long long)nsuper * (rank + 1) / nranks);
-  c->chunk0 = s0 * FEA_SUPER_CHUNKS;
-  c->nchunks_local = (s1 * FEA_SUPER_CHUNKS < c->nchunks ? s1 * FEA_SUPER_CHUNKS : c->nchunks) - c->chunk0;
-  if (!c->h_super_achunk.empty()) {
-    c->achunk0 = c->h_super_achunk[s0];
-    c->nachunks_local = c->h_super_achunk[s1] - c->achunk0;
-  }
-  return FEAHIP_OK;
+  return install_shard(c, rank, nranks);
 }
 
 extern "C" int feahip_update_nodes_with_bc(feahip_ctx *c, double lambda)
@@ -287,18 +282,15 @@ extern "C" int feahip_energy(feahip_ctx *c, double *tolerance)
 {
   CTX_GUARD(c);
   if (!tolerance) return FEAHIP_EINVAL;
-  return launch_dot(c, c->d_f, c->d_u, tolerance);
+  std::vector<feahip_ctx *> R(1, c);
+  return dist_energy(R, tolerance);
 }
 
 extern "C" int feahip_update_nodes_with_solution(feahip_ctx *c, const double *u)
 {
   CTX_GUARD(c);
-  c->state_valid = false;
-  if (u) {
-    FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_q, u, sizeof(double) * (size_t)c->ndof, hipMemcpyHostToDevice, c->stream));
-    return launch_update_nodes_solution(c, c->d_q);
-  }
-  return launch_update_nodes_solution(c, c->d_u);
+  std::vector<feahip_ctx *> R(1, c);
+  return dist_update_nodes_with_solution(R, u);
 }
 
 extern "C" int feahip_solve(feahip_ctx *c, int load_increments, int max_newton, int modified_newton,
@@ -307,37 +299,125 @@ extern "C" int feahip_solve(feahip_ctx *c, int load_increments, int max_newton, 
                             int *steps_done)
 {
   CTX_GUARD(c);
-  int rc, nlog = 0, step = 0;
-  for (; step < load_increments; ++step) {                       // fea_solver.c:163
-    int it = 0;
-    double tolerance = 0;
-    if ((rc = feahip_update_nodes_with_bc(c, 1.0))) return rc;   // :168
-    if ((rc = feahip_update_state(c, nullptr))) return rc;       // :171-174
-    if ((rc = feahip_create_stiffness(c))) return rc;            // :177
-    if (modified_newton && (rc = feahip_stash_stiffness(c))) return rc;   // :179
-    do {
-      it++;
-      if (modified_newton) {
-        if ((rc = feahip_create_residual_forces(c))) return rc;  // :185
-        if ((rc = feahip_restore_stiffness(c))) return rc;       // :194-195
-      } else if (it == 1) {
-        if ((rc = feahip_create_residual_forces(c))) return rc;  // K of :177 is current
-      } else {
-        if ((rc = feahip_create_stiffness_and_residual(c))) return rc;   // :185 + :200
-      }
-      if ((rc = feahip_apply_prescribed_bc(c, 0.0))) return rc;  // :203
-      if ((rc = feahip_solve_slae(c, solver_type, solver_tolerance, solver_max_iter, nullptr, nullptr))) return rc;  // :205
-      if ((rc = feahip_energy(c, &tolerance))) return rc;        // :208-210
-      if (tol_log && nlog < tol_log_cap) tol_log[nlog] = tolerance;
-      nlog++;
-      if ((rc = feahip_update_nodes_with_solution(c, nullptr))) return rc;   // :216
-      if ((rc = feahip_update_state(c, nullptr))) return rc;     // :217-218
-    } while (fabs(tolerance) > desired_tolerance && it < max_newton);      // :220-221
-    if (its_log) its_log[step] = it;
-    if (it == max_newton) break;                                 // :225-231
+  std::vector<feahip_ctx *> R(1, c);
+  return dist_newton(R, load_increments, max_newton, modified_newton, desired_tolerance, solver_type,
+                     solver_tolerance, solver_max_iter, tol_log, tol_log_cap, its_log, steps_done);
+}
+
+// ---- sharding ------------------------------------------------------------
+
+static void drop_transport(feahip_ctx *c)
+{
+  if (c->tr && c->owns_tr) delete c->tr;
+  c->tr = nullptr; c->owns_tr = false;
+}
+
+extern "C" int feahip_comm_unique_id(void *out, int cap) { return rccl_unique_id(out, cap); }
+
+extern "C" int feahip_comm_init(feahip_ctx *c, int rank, int nranks, const void *unique_id)
+{
+  CTX_GUARD(c);
+  if (!unique_id) return FEAHIP_EINVAL;
+  int rc = install_shard(c, rank, nranks);
+  if (rc) return rc;
+  drop_transport(c);
+  c->tr = make_rccl_transport(c, rank, nranks, unique_id, c->err);
+  if (!c->tr) return FEAHIP_ECOMM;
+  c->owns_tr = true;
+  return FEAHIP_OK;
+}
+
+extern "C" int feahip_group_init(feahip_ctx **ctxs, int n)
+{
+  if (!ctxs || n < 1) return FEAHIP_EINVAL;
+  Transport *t = make_group_transport();
+  for (int r = 0; r < n; ++r) {
+    if (!ctxs[r]) { delete t; return FEAHIP_EINVAL; }
+    (void)hipSetDevice(ctxs[r]->device);
+    int rc = install_shard(ctxs[r], r, n);
+    if (rc) { delete t; return rc; }
+    drop_transport(ctxs[r]);
+    ctxs[r]->tr = t;
+    ctxs[r]->owns_tr = (r == 0);
   }
-  if (steps_done) *steps_done = step;
-  FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  return FEAHIP_OK;
+}
+
+static int group_vec(feahip_ctx **ctxs, int n, std::vector<feahip_ctx *> &R)
+{
+  if (!ctxs || n < 1) return FEAHIP_EINVAL;
+  R.assign(ctxs, ctxs + n);
+  for (int r = 0; r < n; ++r)
+    if (!R[r] || R[r]->nranks != n || R[r]->rank != r || !R[r]->tr) {
+      if (R[0]) R[0]->err = "not a group: call feahip_group_init on these contexts first";
+      return FEAHIP_ESTATE;
+    }
+  return FEAHIP_OK;
+}
+
+extern "C" int feahip_group_solve_slae(feahip_ctx **ctxs, int n, int type, double tol, int max_iter, int *iters, double *resid)
+{
+  std::vector<feahip_ctx *> R;
+  int rc = group_vec(ctxs, n, R);
+  if (rc) return rc;
+  return dist_solve_pcg(R, type, tol, max_iter, iters, resid);
+}
+
+extern "C" int feahip_group_energy(feahip_ctx **ctxs, int n, double *tolerance)
+{
+  std::vector<feahip_ctx *> R;
+  int rc = group_vec(ctxs, n, R);
+  if (rc) return rc;
+  return dist_energy(R, tolerance);
+}
+
+extern "C" int feahip_group_update_nodes_with_solution(feahip_ctx **ctxs, int n)
+{
+  std::vector<feahip_ctx *> R;
+  int rc = group_vec(ctxs, n, R);
+  if (rc) return rc;
+  return dist_update_nodes_with_solution(R, nullptr);
+}
+
+extern "C" int feahip_group_solve(feahip_ctx **ctxs, int n, int load_increments, int max_newton, int modified_newton,
+                                  double desired_tolerance, int solver_type, double solver_tolerance,
+                                  int solver_max_iter, double *tol_log, int tol_log_cap, int *its_log, int *steps_done)
+{
+  std::vector<feahip_ctx *> R;
+  int rc = group_vec(ctxs, n, R);
+  if (rc) return rc;
+  return dist_newton(R, load_increments, max_newton, modified_newton, desired_tolerance, solver_type,
+                     solver_tolerance, solver_max_iter, tol_log, tol_log_cap, its_log, steps_done);
+}
+
+extern "C" int feahip_owned_rows(feahip_ctx *c, int *row0, int *row1)
+{
+  if (!c || !row0 || !row1) return FEAHIP_EINVAL;
+  *row0 = c->row0; *row1 = c->row1;
+  return FEAHIP_OK;
+}
+
+// Host-only: the halo plan of one rank, from the element->node map alone (no
+// device is touched).  Lists are written into caller buffers sized by a first
+// call with null lists: counts[0] = npeers, [1] = total send, [2] = total recv,
+// [3] = row0, [4] = row1.
+extern "C" int feahip_shard_plan(int n_nodes, int n_elems, int npe, const int *elements, int rank, int nranks,
+                                 int *counts, int *peers, int *send_off, int *recv_off, int *send_idx, int *recv_idx)
+{
+  if (!elements || !counts || n_nodes <= 0 || n_elems <= 0 || nranks < 1 || rank < 0 || rank >= nranks) return FEAHIP_EINVAL;
+  HostPattern hp;
+  std::string err;
+  int rc = build_host_pattern(n_nodes, n_elems, npe, elements, hp, err);
+  if (rc) return rc;
+  ShardPlan plan;
+  build_shard_plan(hp.rowptr, hp.colidx, hp.chunk, rank, nranks, plan);
+  counts[0] = (int)plan.peer.size(); counts[1] = (int)plan.send_idx.size(); counts[2] = (int)plan.recv_idx.size();
+  counts[3] = plan.row0; counts[4] = plan.row1;
+  if (peers) std::copy(plan.peer.begin(), plan.peer.end(), peers);
+  if (send_off) std::copy(plan.send_off.begin(), plan.send_off.end(), send_off);
+  if (recv_off) std::copy(plan.recv_off.begin(), plan.recv_off.end(), recv_off);
+  if (send_idx) std::copy(plan.send_idx.begin(), plan.send_idx.end(), send_idx);
+  if (recv_idx) std::copy(plan.recv_idx.begin(), plan.recv_idx.end(), recv_idx);
   return FEAHIP_OK;
 }
 
@@ -350,8 +430,8 @@ extern "C" int feahip_set_nodes(feahip_ctx *c, const double *nodes)
   std::vector<double> pad((size_t)c->N * 4, 0.0);
   for (int a = 0; a < c->N; ++a)
     for (int j = 0; j < 3; ++j) pad[(size_t)a * 4 + j] = nodes[(size_t)a * 3 + j];
+  FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_x, pad.data(), sizeof(double) * pad.size(), hipMemcpyHostToDevice, c->stream));
   FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-  FEA_HIP_CHECK(c, hipMemcpy(c->d_x, pad.data(), sizeof(double) * pad.size(), hipMemcpyHostToDevice));
   c->state_valid = false;
   return FEAHIP_OK;
 }
@@ -361,8 +441,8 @@ extern "C" int feahip_get_nodes(feahip_ctx *c, double *nodes)
   CTX_GUARD(c);
   if (!nodes) return FEAHIP_EINVAL;
   std::vector<double> pad((size_t)c->N * 4);
+  FEA_HIP_CHECK(c, hipMemcpyAsync(pad.data(), c->d_x, sizeof(double) * pad.size(), hipMemcpyDeviceToHost, c->stream));
   FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-  FEA_HIP_CHECK(c, hipMemcpy(pad.data(), c->d_x, sizeof(double) * pad.size(), hipMemcpyDeviceToHost));
   for (int a = 0; a < c->N; ++a)
     for (int j = 0; j < 3; ++j) nodes[(size_t)a * 3 + j] = pad[(size_t)a * 4 + j];
   return FEAHIP_OK;
@@ -371,8 +451,8 @@ extern "C" int feahip_get_nodes(feahip_ctx *c, double *nodes)
 static int get_vec(feahip_ctx *c, const double *d, double *h, size_t n)
 {
   if (!h) return FEAHIP_EINVAL;
+  FEA_HIP_CHECK(c, hipMemcpyAsync(h, d, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
   FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-  FEA_HIP_CHECK(c, hipMemcpy(h, d, sizeof(double) * n, hipMemcpyDeviceToHost));
   return FEAHIP_OK;
 }
 
@@ -383,8 +463,8 @@ extern "C" int feahip_set_forces(feahip_ctx *c, const double *f)
 {
   CTX_GUARD(c);
   if (!f) return FEAHIP_EINVAL;
+  FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_f, f, sizeof(double) * (size_t)c->ndof, hipMemcpyHostToDevice, c->stream));
   FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-  FEA_HIP_CHECK(c, hipMemcpy(c->d_f, f, sizeof(double) * (size_t)c->ndof, hipMemcpyHostToDevice));
   return FEAHIP_OK;
 }
 
@@ -453,8 +533,8 @@ extern "C" int feahip_spmv(feahip_ctx *c, const double *x, double *y)
 {
   CTX_GUARD(c);
   if (!x || !y) return FEAHIP_EINVAL;
+  FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_p, x, sizeof(double) * (size_t)c->ndof, hipMemcpyHostToDevice, c->stream));
   FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-  FEA_HIP_CHECK(c, hipMemcpy(c->d_p, x, sizeof(double) * (size_t)c->ndof, hipMemcpyHostToDevice));
   int rc = launch_spmv(c, c->d_p, c->d_q);
   if (rc) return rc;
   return get_vec(c, c->d_q, y, (size_t)c->ndof);

@@ -37,7 +37,15 @@ struct feahip_ctx {
   int nchunks = 0;
   int chunk0 = 0, nchunks_local = 0;  // this rank's share of the chunks (row shard)
   int nachunks = 0, achunk0 = 0, nachunks_local = 0;   // same for the staged kernel's partition
-  std::vector<int> h_super_achunk;
+  std::vector<int> h_super_achunk, h_chunk;
+  // row shard of a multi-rank solve: this rank owns nodes [row0, row1)
+  int rank = 0, nranks = 1, row0 = 0, row1 = 0;
+  struct Transport *tr = nullptr;      // null: single rank, no exchange
+  bool owns_tr = false;
+  std::vector<int> peer, send_off, recv_off;   // halo plan: per peer, ranges into the index lists
+  int nsend = 0, nrecv = 0;
+  int *d_send_idx = nullptr, *d_recv_idx = nullptr;
+  double *d_send_buf = nullptr, *d_recv_buf = nullptr;
   int max_rowlen = 0;
   bool linear_tet = false;    // npe == 4 and dN is the constant-strain table
   int model = 0;
@@ -178,5 +186,36 @@ int launch_update_nodes_solution(feahip_ctx *c, const double *d_u);
 int launch_spmv(feahip_ctx *c, const double *d_xv, double *d_yv);
 int solve_pcg(feahip_ctx *c, int type, double tol, int max_iter, int *iters,
               double *resid);
-int launch_dot(feahip_ctx *c, const double *a, const double *b, double *out_host);
 int time_pcg_iteration(feahip_ctx *c, int warmup, int iters, double *avg_ms);
+
+// shard.cpp -- host-only plan of a row-sharded solve
+struct ShardPlan {
+  int rank = 0, nranks = 1, row0 = 0, row1 = 0;
+  std::vector<int> peer, send_off, recv_off;   // [npeer], [npeer+1], [npeer+1]
+  std::vector<int> send_idx, recv_idx;         // node ids, ascending inside every peer segment
+};
+// rows of rank k = rows of supers [nsuper*k/n, nsuper*(k+1)/n); chunk = SpMV chunk partition
+void shard_row_range(const std::vector<int> &chunk, int rank, int nranks, int &row0, int &row1);
+void build_shard_plan(const std::vector<int> &rowptr, const std::vector<int> &colidx,
+                      const std::vector<int> &chunk, int rank, int nranks, ShardPlan &plan);
+
+// multi-rank operations (kernels_solve.hip).  R = the ranks driven by this
+// process: one context with the RCCL transport, or all contexts of an
+// in-process group.
+struct Transport {
+  virtual ~Transport() {}
+  // halo rows of vector `which` (0 = p, 1 = u, 2 = x) from their owners
+  virtual int exchange(std::vector<feahip_ctx *> &R, int which) = 0;
+  // d_scal[8+slot .. 8+slot+n) summed over all ranks, result on every rank
+  virtual int allreduce(std::vector<feahip_ctx *> &R, int slot, int n) = 0;
+};
+Transport *make_group_transport();
+Transport *make_rccl_transport(feahip_ctx *c, int rank, int nranks, const void *unique_id, std::string &err);
+int rccl_unique_id(void *out, int cap);
+int install_shard(feahip_ctx *c, int rank, int nranks);
+int dist_solve_pcg(std::vector<feahip_ctx *> &R, int type, double tol, int max_iter, int *iters, double *resid);
+int dist_energy(std::vector<feahip_ctx *> &R, double *out);
+int dist_update_nodes_with_solution(std::vector<feahip_ctx *> &R, const double *u_host);
+int dist_newton(std::vector<feahip_ctx *> &R, int load_increments, int max_newton, int modified_newton,
+                double desired_tolerance, int solver_type, double solver_tolerance, int solver_max_iter,
+                double *tol_log, int tol_log_cap, int *its_log, int *steps_done);

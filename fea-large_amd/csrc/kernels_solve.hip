@@ -62,10 +62,11 @@ __device__ __forceinline__ int bc_find_block(const int *rowptr, const int *colid
 
 // f[r] -= K[r,c] * p  over the stored rows r of column c (fea_solver.c:1250-1252).
 // Only free rows matter: a constrained row's entry is overwritten by
-// f[c] = K[c,c]*p (:1256) whatever the processing order.
+// f[c] = K[c,c]*p (:1256) whatever the processing order.  A rank of a sharded
+// solve touches the rows it owns, [a0, a1), and nothing else.
 __global__ void k_bc_rhs(int n_cdof, const int *cdof, const double *cval, double lambda,
                          const int *rowptr, const int *colidx, const double *K,
-                         const uint8_t *mask, double *f)
+                         const uint8_t *mask, double *f, int a0, int a1)
 {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_cdof) return;
@@ -74,6 +75,7 @@ __global__ void k_bc_rhs(int n_cdof, const int *cdof, const double *cval, double
   const int c = cdof[t], cn = c / 3, cj = c % 3;
   for (int q = rowptr[cn]; q < rowptr[cn + 1]; ++q) {
     const int b = colidx[q];
+    if (b < a0 || b >= a1) continue;
     const int tb = bc_find_block(rowptr, colidx, b, cn);   // block (b, cn)
     if (tb < 0) continue;
     for (int i = 0; i < 3; ++i) {
@@ -85,23 +87,27 @@ __global__ void k_bc_rhs(int n_cdof, const int *cdof, const double *cval, double
 
 // sp_matrix_cross_cancellation + f[c] = K[c,c]*p (fea_solver.c:1254-1256)
 __global__ void k_bc_cancel(int n_cdof, const int *cdof, const double *cval, double lambda,
-                            const int *rowptr, const int *colidx, double *K, double *f)
+                            const int *rowptr, const int *colidx, double *K, double *f, int a0, int a1)
 {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_cdof) return;
   const int c = cdof[t], cn = c / 3, ci = c % 3;
+  const bool own_row = cn >= a0 && cn < a1;
   for (int q = rowptr[cn]; q < rowptr[cn + 1]; ++q) {
     const int b = colidx[q];
     double *blk = K + (size_t)q * 9;             // block (cn, b): row ci
-    for (int j = 0; j < 3; ++j)
-      if (!(b == cn && j == ci)) blk[3 * ci + j] = 0.0;
-    const int tb = bc_find_block(rowptr, colidx, b, cn);   // block (b, cn): column ci
-    if (tb >= 0) {
-      double *tblk = K + (size_t)tb * 9;
-      for (int i = 0; i < 3; ++i)
-        if (!(b == cn && i == ci)) tblk[3 * i + ci] = 0.0;
+    if (own_row)
+      for (int j = 0; j < 3; ++j)
+        if (!(b == cn && j == ci)) blk[3 * ci + j] = 0.0;
+    if (b >= a0 && b < a1) {
+      const int tb = bc_find_block(rowptr, colidx, b, cn);   // block (b, cn): column ci
+      if (tb >= 0) {
+        double *tblk = K + (size_t)tb * 9;
+        for (int i = 0; i < 3; ++i)
+          if (!(b == cn && i == ci)) tblk[3 * i + ci] = 0.0;
+      }
     }
-    if (b == cn) f[c] = blk[3 * ci + ci] * (cval[t] * lambda);
+    if (b == cn && own_row) f[c] = blk[3 * ci + ci] * (cval[t] * lambda);
   }
 }
 
@@ -128,9 +134,9 @@ int launch_apply_bc(feahip_ctx *c, double lambda)
   const int grid = (c->n_cdof + 255) / 256;
   if (lambda != 0.0)
     hipLaunchKernelGGL(k_bc_rhs, dim3(grid), dim3(256), 0, c->stream, c->n_cdof, c->d_cdof, c->d_cval,
-                       lambda, c->d_rowptr, c->d_colidx, c->d_K, c->d_dofmask, c->d_f);
+                       lambda, c->d_rowptr, c->d_colidx, c->d_K, c->d_dofmask, c->d_f, c->row0, c->row1);
   hipLaunchKernelGGL(k_bc_cancel, dim3(grid), dim3(256), 0, c->stream, c->n_cdof, c->d_cdof, c->d_cval,
-                     lambda, c->d_rowptr, c->d_colidx, c->d_K, c->d_f);
+                     lambda, c->d_rowptr, c->d_colidx, c->d_K, c->d_f, c->row0, c->row1);
   FEA_HIP_CHECK(c, hipGetLastError());
   return FEAHIP_OK;
 }
@@ -222,11 +228,6 @@ static int spmv_grid(const feahip_ctx *c)
   int g = (c->nchunks_local + FEA_WAVES_PER_WG - 1) / FEA_WAVES_PER_WG;
   return g < FEA_RED_BLOCKS ? (g > 0 ? g : 1) : FEA_RED_BLOCKS;
 }
-static int vec_grid(const feahip_ctx *c)
-{
-  int g = (c->ndof + 255) / 256;
-  return g < FEA_RED_BLOCKS ? (g > 0 ? g : 1) : FEA_RED_BLOCKS;
-}
 
 int launch_spmv(feahip_ctx *c, const double *d_xv, double *d_yv)
 {
@@ -238,67 +239,60 @@ int launch_spmv(feahip_ctx *c, const double *d_xv, double *d_yv)
 }
 
 // ------------------------------------------------------------------------
-// dot product (two-stage, fixed order)
+// dot product over the owned rows (two-stage, fixed order)
 // ------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
-void k_dot_partial(int n, const double *a, const double *b, double *part)
+void k_dot_partial(int i0, int i1, const double *a, const double *b, double *part)
 {
   __shared__ double scratch[5];
   double v = 0;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) v += a[i] * b[i];
+  for (int i = i0 + blockIdx.x * 256 + threadIdx.x; i < i1; i += gridDim.x * 256) v += a[i] * b[i];
   v = block_sum(v, scratch);
   if (threadIdx.x == 0) part[blockIdx.x] = v;
 }
 
+// out[k] = sum of part[k*stride .. k*stride+n)  for k < nsums  (one block)
 __global__ __launch_bounds__(256)
-void k_reduce_final(int n, const double *part, double *out)
+void k_reduce_final(int n, int nsums, int stride, const double *part, double *out)
 {
   __shared__ double scratch[5];
-  const double v = reduce_partials(part, n, scratch);
-  if (threadIdx.x == 0) out[0] = v;
-}
-
-int launch_dot(feahip_ctx *c, const double *a, const double *b, double *out_host)
-{
-  const int g = vec_grid(c);
-  hipLaunchKernelGGL(k_dot_partial, dim3(g), dim3(256), 0, c->stream, c->ndof, a, b, c->d_part);
-  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, g, c->d_part, c->d_scal + 8);
-  FEA_HIP_CHECK(c, hipGetLastError());
-  FEA_HIP_CHECK(c, hipMemcpyAsync(out_host, c->d_scal + 8, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-  return FEAHIP_OK;
+  for (int k = 0; k < nsums; ++k) {
+    const double v = reduce_partials(part + (size_t)k * stride, n, scratch);
+    if (threadIdx.x == 0) out[k] = v;
+  }
 }
 
 // ------------------------------------------------------------------------
 // preconditioned conjugate gradients
 //
 // Device scalars (d_scal): [0],[1] r.z ping-pong, [2] b.b, [3] last r.r,
-// [4] tolerance^2.  d_flag[0] = iteration at which the stop test fired
-// (0 = still running, <0 = breakdown).  Partial-sum arrays live in d_part:
-// [0..RB) p.q, [RB..2RB) r.z, [2RB..3RB) r.r, [3RB..4RB) b.b.
+// [4] tolerance^2, [8..11] reduction results / all-reduce buffer.
+// d_flag[0] = iteration at which the stop test fired (0 = still running,
+// <0 = breakdown).  Partial-sum arrays in d_part: [0..RB) p.q, [RB..2RB) r.z,
+// [2RB..3RB) r.r, [3RB..4RB) b.b.
+// A rank of a sharded solve owns the nodes [a0, a1); every kernel below
+// touches owned rows only.  gred != nullptr: the sums have already been
+// reduced over all ranks (all-reduce) and are read from gred instead of the
+// partial arrays.
 // ------------------------------------------------------------------------
 #define RB FEA_RED_BLOCKS
 
 // 3x3 inverse of the diagonal blocks (block-Jacobi); mode 0 = identity
-__global__ void k_precond_build(int N, const int *rowptr, const int *colidx, const double *K,
-                                int mode, double *minv)
+__global__ void k_precond_build(int a0, int a1, const int *diag, const double *K, int mode, double *minv)
 {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= N) return;
+  const int a = a0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= a1) return;
   double *o = minv + (size_t)a * 9;
   double m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   if (mode != 0) {
-    const int q = bc_find_block(rowptr, colidx, a, a);
-    if (q >= 0) {
-      const double *d = K + (size_t)q * 9;
-      const double det = d[0] * (d[4] * d[8] - d[5] * d[7]) - d[1] * (d[3] * d[8] - d[5] * d[6]) +
-                         d[2] * (d[3] * d[7] - d[4] * d[6]);
-      if (det != 0.0 && det == det) {
-        const double id = 1.0 / det;
-        m[0] = (d[4] * d[8] - d[5] * d[7]) * id; m[1] = (d[2] * d[7] - d[1] * d[8]) * id; m[2] = (d[1] * d[5] - d[2] * d[4]) * id;
-        m[3] = (d[5] * d[6] - d[3] * d[8]) * id; m[4] = (d[0] * d[8] - d[2] * d[6]) * id; m[5] = (d[2] * d[3] - d[0] * d[5]) * id;
-        m[6] = (d[3] * d[7] - d[4] * d[6]) * id; m[7] = (d[1] * d[6] - d[0] * d[7]) * id; m[8] = (d[0] * d[4] - d[1] * d[3]) * id;
-      }
+    const double *d = K + (size_t)diag[a] * 9;
+    const double det = d[0] * (d[4] * d[8] - d[5] * d[7]) - d[1] * (d[3] * d[8] - d[5] * d[6]) +
+                       d[2] * (d[3] * d[7] - d[4] * d[6]);
+    if (det != 0.0 && det == det) {
+      const double id = 1.0 / det;
+      m[0] = (d[4] * d[8] - d[5] * d[7]) * id; m[1] = (d[2] * d[7] - d[1] * d[8]) * id; m[2] = (d[1] * d[5] - d[2] * d[4]) * id;
+      m[3] = (d[5] * d[6] - d[3] * d[8]) * id; m[4] = (d[0] * d[8] - d[2] * d[6]) * id; m[5] = (d[2] * d[3] - d[0] * d[5]) * id;
+      m[6] = (d[3] * d[7] - d[4] * d[6]) * id; m[7] = (d[1] * d[6] - d[0] * d[7]) * id; m[8] = (d[0] * d[4] - d[1] * d[3]) * id;
     }
   }
   for (int i = 0; i < 9; ++i) o[i] = m[i];
@@ -306,12 +300,12 @@ __global__ void k_precond_build(int N, const int *rowptr, const int *colidx, con
 
 // r = b - q ; p = M r ; partial sums r.z, r.r, b.b     (q = A x0, x0 = b)
 __global__ __launch_bounds__(256)
-void k_cg_init(int N, const double *b, const double *q, const double *minv, double *r, double *p,
+void k_cg_init(int a0, int a1, const double *b, const double *q, const double *minv, double *r, double *p,
                double *part)
 {
   __shared__ double scratch[5];
   double srz = 0, srr = 0, sbb = 0;
-  for (int a = blockIdx.x * 256 + threadIdx.x; a < N; a += gridDim.x * 256) {
+  for (int a = a0 + blockIdx.x * 256 + threadIdx.x; a < a1; a += gridDim.x * 256) {
     const double *m = minv + (size_t)a * 9;
     double rv[3], bv[3];
     for (int i = 0; i < 3; ++i) {
@@ -329,13 +323,18 @@ void k_cg_init(int N, const double *b, const double *q, const double *minv, doub
   if (threadIdx.x == 0) { part[RB + blockIdx.x] = srz; part[2 * RB + blockIdx.x] = srr; part[3 * RB + blockIdx.x] = sbb; }
 }
 
+// gred (if given) holds {r.z, r.r, b.b} summed over all ranks
 __global__ __launch_bounds__(256)
-void k_cg_init_scalars(int nparts, const double *part, double *scal, double tol, int *flag)
+void k_cg_init_scalars(int nparts, const double *part, const double *gred, double *scal, double tol, int *flag)
 {
   __shared__ double scratch[5];
-  const double rz = reduce_partials(part + RB, nparts, scratch);
-  const double rr = reduce_partials(part + 2 * RB, nparts, scratch);
-  const double bb = reduce_partials(part + 3 * RB, nparts, scratch);
+  double rz, rr, bb;
+  if (gred) { rz = gred[0]; rr = gred[1]; bb = gred[2]; }
+  else {
+    rz = reduce_partials(part + RB, nparts, scratch);
+    rr = reduce_partials(part + 2 * RB, nparts, scratch);
+    bb = reduce_partials(part + 3 * RB, nparts, scratch);
+  }
   if (threadIdx.x == 0) {
     scal[0] = rz; scal[1] = rz; scal[2] = bb; scal[3] = rr; scal[4] = tol * tol;
     // a zero right-hand side (or an exact start vector) is already solved
@@ -345,16 +344,16 @@ void k_cg_init_scalars(int nparts, const double *part, double *scal, double tol,
 
 // alpha = r.z / p.q ; x += alpha p ; r -= alpha q ; partial sums of r.Mr, r.r
 __global__ __launch_bounds__(256)
-void k_cg_update(int N, int it, int n_pq, const double *p, const double *q, const double *minv,
-                 double *x, double *r, double *part, const double *scal, const int *flag)
+void k_cg_update(int a0, int a1, int it, int n_pq, const double *p, const double *q, const double *minv,
+                 double *x, double *r, double *part, const double *gred, const double *scal, const int *flag)
 {
   __shared__ double scratch[5];
   if (flag[0] != 0) return;
-  const double pq = reduce_partials(part, n_pq, scratch);
+  const double pq = gred ? gred[0] : reduce_partials(part, n_pq, scratch);
   const double rz = scal[it & 1];
   const double alpha = rz / pq;
   double srz = 0, srr = 0;
-  for (int a = blockIdx.x * 256 + threadIdx.x; a < N; a += gridDim.x * 256) {
+  for (int a = a0 + blockIdx.x * 256 + threadIdx.x; a < a1; a += gridDim.x * 256) {
     const double *m = minv + (size_t)a * 9;
     double rv[3];
     for (int i = 0; i < 3; ++i) {
@@ -373,20 +372,21 @@ void k_cg_update(int N, int it, int n_pq, const double *p, const double *q, cons
 }
 
 // beta = r.z_new / r.z_old ; p = M r + beta p ; stop test on r.r
+// gred (if given) holds {r.z_new, r.r} summed over all ranks
 __global__ __launch_bounds__(256)
-void k_cg_direction(int N, int it, int nparts, const double *r, const double *minv, double *p,
-                    const double *part, double *scal, int *flag)
+void k_cg_direction(int a0, int a1, int it, int nparts, const double *r, const double *minv, double *p,
+                    const double *part, const double *gred, double *scal, int *flag)
 {
   __shared__ double scratch[5];
   if (flag[0] != 0) return;
-  const double rz_new = reduce_partials(part + RB, nparts, scratch);
-  const double rr = reduce_partials(part + 2 * RB, nparts, scratch);
+  const double rz_new = gred ? gred[0] : reduce_partials(part + RB, nparts, scratch);
+  const double rr = gred ? gred[1] : reduce_partials(part + 2 * RB, nparts, scratch);
   const double rz_old = scal[it & 1];
   const bool stop = rr <= scal[4] * scal[2];
   const bool broke = !(rz_new == rz_new) || !(rr == rr) || rz_old == 0.0;
   if (!stop && !broke) {
     const double beta = rz_new / rz_old;
-    for (int a = blockIdx.x * 256 + threadIdx.x; a < N; a += gridDim.x * 256) {
+    for (int a = a0 + blockIdx.x * 256 + threadIdx.x; a < a1; a += gridDim.x * 256) {
       const double *m = minv + (size_t)a * 9;
       const double r0 = r[(size_t)a * 3], r1 = r[(size_t)a * 3 + 1], r2 = r[(size_t)a * 3 + 2];
       for (int i = 0; i < 3; ++i) {
@@ -395,10 +395,9 @@ void k_cg_direction(int N, int it, int nparts, const double *r, const double *mi
       }
     }
   }
-  // every block has read scal[it&1] and flag[0] before anyone writes: the
-  // writes below go to the other ping-pong slot; the flag is only read at
-  // kernel entry, and the early return above happens before this point in
-  // every block of THIS launch (flag was 0 for all of them).
+  // The writes below go to the other ping-pong slot of scal; the flag is read
+  // only at kernel entry.  A block of THIS launch that starts after the flag
+  // was set returns early, which is what stop / broke would have made it do.
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     scal[(it + 1) & 1] = rz_new;
     scal[3] = rr;
@@ -407,49 +406,210 @@ void k_cg_direction(int N, int it, int nparts, const double *r, const double *mi
   }
 }
 
-static void enqueue_cg_iteration(feahip_ctx *c, int it)
+// halo rows of a 3N vector: buf[3i+j] = v[3 idx[i] + j] and back
+__global__ void k_halo_pack(int n, const int *idx, const double *v, int vstride, double *buf)
 {
-  const int gs = spmv_grid(c), gv = vec_grid(c);
-  hipLaunchKernelGGL(k_spmv, dim3(gs), dim3(256), 0, c->stream, c->chunk0, c->nchunks_local, c->d_chunk, c->d_rowptr,
-                     c->d_colidx, c->d_K, c->d_p, c->d_q, c->d_p, c->d_part, c->d_flag);
-  hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(256), 0, c->stream, c->N, it, gs, c->d_p, c->d_q,
-                     c->d_minv, c->d_u, c->d_r, c->d_part, c->d_scal, c->d_flag);
-  hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(256), 0, c->stream, c->N, it, gv, c->d_r,
-                     c->d_minv, c->d_p, c->d_part, c->d_scal, c->d_flag);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * 3) return;
+  buf[t] = v[(size_t)idx[t / 3] * vstride + t % 3];
+}
+__global__ void k_halo_unpack(int n, const int *idx, const double *buf, int vstride, double *v)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * 3) return;
+  v[(size_t)idx[t / 3] * vstride + t % 3] = buf[t];
+}
+
+static int vec_grid_range(int n)
+{
+  int g = (n + 255) / 256;
+  return g < FEA_RED_BLOCKS ? (g > 0 ? g : 1) : FEA_RED_BLOCKS;
+}
+
+// ------------------------------------------------------------------------
+// launch helpers (one rank)
+// ------------------------------------------------------------------------
+static inline int own0(const feahip_ctx *c) { return c->row0; }
+static inline int own1(const feahip_ctx *c) { return c->row1; }
+static inline int vgrid(const feahip_ctx *c) { return vec_grid_range(c->row1 - c->row0); }
+
+static void enq_precond(feahip_ctx *c, int mode)
+{
+  const int n = own1(c) - own0(c);
+  hipLaunchKernelGGL(k_precond_build, dim3((n + 255) / 256 > 0 ? (n + 255) / 256 : 1), dim3(256), 0, c->stream,
+                     own0(c), own1(c), c->d_diag, c->d_K, mode, c->d_minv);
+}
+
+static void enq_spmv_dot(feahip_ctx *c, const double *xv, double *yv, const double *dotwith, double *part)
+{
+  hipLaunchKernelGGL(k_spmv, dim3(spmv_grid(c)), dim3(256), 0, c->stream, c->chunk0, c->nchunks_local, c->d_chunk,
+                     c->d_rowptr, c->d_colidx, c->d_K, xv, yv, dotwith, part, dotwith ? c->d_flag : (const int *)nullptr);
+}
+
+// ------------------------------------------------------------------------
+// transports
+// ------------------------------------------------------------------------
+static double *halo_vec(feahip_ctx *c, int which, int &stride)
+{
+  stride = (which == 2) ? 4 : 3;
+  return which == 0 ? c->d_p : (which == 1 ? c->d_u : c->d_x);
+}
+
+static void enq_pack(feahip_ctx *c, int which)
+{
+  if (c->nsend <= 0) return;
+  int stride; double *v = halo_vec(c, which, stride);
+  hipLaunchKernelGGL(k_halo_pack, dim3((c->nsend * 3 + 255) / 256), dim3(256), 0, c->stream, c->nsend,
+                     c->d_send_idx, v, stride, c->d_send_buf);
+}
+
+static void enq_unpack(feahip_ctx *c, int which)
+{
+  if (c->nrecv <= 0) return;
+  int stride; double *v = halo_vec(c, which, stride);
+  hipLaunchKernelGGL(k_halo_unpack, dim3((c->nrecv * 3 + 255) / 256), dim3(256), 0, c->stream, c->nrecv,
+                     c->d_recv_idx, c->d_recv_buf, stride, v);
+}
+
+void feahip_enq_pack(feahip_ctx *c, double *v, int stride)
+{
+  if (c->nsend <= 0) return;
+  hipLaunchKernelGGL(k_halo_pack, dim3((c->nsend * 3 + 255) / 256), dim3(256), 0, c->stream, c->nsend,
+                     c->d_send_idx, v, stride, c->d_send_buf);
+}
+void feahip_enq_unpack(feahip_ctx *c, double *v, int stride)
+{
+  if (c->nrecv <= 0) return;
+  hipLaunchKernelGGL(k_halo_unpack, dim3((c->nrecv * 3 + 255) / 256), dim3(256), 0, c->stream, c->nrecv,
+                     c->d_recv_idx, c->d_recv_buf, stride, v);
+}
+
+// All ranks live in this process (any mix of devices): copies between the
+// ranks' buffers, sums on the host.  Used by the in-process group API -- the
+// way to run and test the sharded solve where one process sees the GPUs.
+struct GroupTransport : Transport {
+  int exchange(std::vector<feahip_ctx *> &R, int which) override
+  {
+    for (auto *c : R) { (void)hipSetDevice(c->device); enq_pack(c, which); }
+    for (auto *c : R) { (void)hipSetDevice(c->device); FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream)); }
+    for (auto *a : R)
+      for (size_t k = 0; k < a->peer.size(); ++k) {
+        feahip_ctx *b = R[(size_t)a->peer[k]];
+        size_t kb = 0;
+        while (kb < b->peer.size() && b->peer[kb] != a->rank) ++kb;
+        const int n = a->send_off[k + 1] - a->send_off[k];
+        if (kb == b->peer.size() || b->recv_off[kb + 1] - b->recv_off[kb] != n) {
+          a->err = "halo plans of two ranks disagree"; return FEAHIP_ECOMM;
+        }
+        // on the RECEIVER's stream: ordered before its unpack kernel (a blocking
+        // hipMemcpy on the null stream is not ordered against a non-blocking stream)
+        (void)hipSetDevice(b->device);
+        FEA_HIP_CHECK(b, hipMemcpyAsync(b->d_recv_buf + (size_t)3 * b->recv_off[kb], a->d_send_buf + (size_t)3 * a->send_off[k],
+                                        sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToDevice, b->stream));
+      }
+    for (auto *c : R) { (void)hipSetDevice(c->device); enq_unpack(c, which); }
+    return FEAHIP_OK;
+  }
+  int allreduce(std::vector<feahip_ctx *> &R, int slot, int n) override
+  {
+    double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tmp[8];
+    for (auto *c : R) {                          // fixed rank order: reproducible
+      (void)hipSetDevice(c->device);
+      FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+      FEA_HIP_CHECK(c, hipMemcpyAsync(tmp, c->d_scal + 8 + slot, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+      FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+      for (int i = 0; i < n; ++i) sum[i] += tmp[i];
+    }
+    for (auto *c : R) {
+      (void)hipSetDevice(c->device);
+      FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_scal + 8 + slot, sum, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+      FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    }
+    return FEAHIP_OK;
+  }
+};
+Transport *make_group_transport() { return new GroupTransport(); }
+
+// ------------------------------------------------------------------------
+// multi-rank PCG.  With one rank and no transport this is the plain solver.
+// ------------------------------------------------------------------------
+#define FOR_RANKS(c) for (feahip_ctx *c : R) if (hipSetDevice(c->device) == hipSuccess)
+
+static int enq_cg_iteration(std::vector<feahip_ctx *> &R, Transport *T, int it)
+{
+  int rc;
+  if (T && (rc = T->exchange(R, 0))) return rc;                  // halo rows of p
+  FOR_RANKS(c) {
+    enq_spmv_dot(c, c->d_p, c->d_q, c->d_p, c->d_part);
+    if (T) hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, spmv_grid(c), 1, RB, c->d_part, c->d_scal + 8);
+  }
+  if (T && (rc = T->allreduce(R, 0, 1))) return rc;              // p.q
+  FOR_RANKS(c) {
+    const int gv = vgrid(c);
+    hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(256), 0, c->stream, own0(c), own1(c), it, spmv_grid(c), c->d_p,
+                       c->d_q, c->d_minv, c->d_u, c->d_r, c->d_part, T ? c->d_scal + 8 : (const double *)nullptr,
+                       c->d_scal, c->d_flag);
+    if (T) hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, gv, 2, RB, c->d_part + RB, c->d_scal + 9);
+  }
+  if (T && (rc = T->allreduce(R, 1, 2))) return rc;              // r.z, r.r
+  FOR_RANKS(c) {
+    const int gv = vgrid(c);
+    hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(256), 0, c->stream, own0(c), own1(c), it, gv, c->d_r, c->d_minv,
+                       c->d_p, c->d_part, T ? c->d_scal + 9 : (const double *)nullptr, c->d_scal, c->d_flag);
+  }
+  return FEAHIP_OK;
+}
+
+static int enq_cg_start(std::vector<feahip_ctx *> &R, Transport *T, int mode, double tol)
+{
+  int rc;
+  FOR_RANKS(c) {
+    enq_precond(c, mode);
+    FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_u, c->d_f, sizeof(double) * (size_t)c->ndof, hipMemcpyDeviceToDevice, c->stream));
+  }
+  if (T && (rc = T->exchange(R, 1))) return rc;                  // halo rows of u0 = f
+  FOR_RANKS(c) {
+    const int gv = vgrid(c);
+    enq_spmv_dot(c, c->d_u, c->d_q, nullptr, nullptr);
+    hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(256), 0, c->stream, own0(c), own1(c), c->d_f, c->d_q, c->d_minv,
+                       c->d_r, c->d_p, c->d_part);
+    if (T) hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, gv, 3, RB, c->d_part + RB, c->d_scal + 8);
+  }
+  if (T && (rc = T->allreduce(R, 0, 3))) return rc;              // r.z, r.r, b.b
+  FOR_RANKS(c) {
+    hipLaunchKernelGGL(k_cg_init_scalars, dim3(1), dim3(256), 0, c->stream, vgrid(c), c->d_part,
+                       T ? c->d_scal + 8 : (const double *)nullptr, c->d_scal, tol, c->d_flag);
+    FEA_HIP_CHECK(c, hipGetLastError());
+  }
+  return FEAHIP_OK;
 }
 
 // Solves K u = f by (preconditioned) CG started from u0 = f, the start vector
 // the reference hands to sp_matrix_yale_solve_cg (fea_solver.c:251-256).
-int solve_pcg(feahip_ctx *c, int type, double tol, int max_iter, int *iters, double *resid)
+int dist_solve_pcg(std::vector<feahip_ctx *> &R, int type, double tol, int max_iter, int *iters, double *resid)
 {
-  const int gv = vec_grid(c);
+  Transport *T = R[0]->tr;
+  feahip_ctx *c0 = R[0];
   const int mode = (type == FEAHIP_CG) ? 0 : 1;
   if (type == FEAHIP_CHOLESKY) { tol = 1e-16; if (max_iter < 100000) max_iter = 100000; }
-  hipLaunchKernelGGL(k_precond_build, dim3((c->N + 255) / 256), dim3(256), 0, c->stream, c->N,
-                     c->d_rowptr, c->d_colidx, c->d_K, mode, c->d_minv);
-  FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_u, c->d_f, sizeof(double) * (size_t)c->ndof,
-                                  hipMemcpyDeviceToDevice, c->stream));
-  int rc = launch_spmv(c, c->d_u, c->d_q);
+  int rc = enq_cg_start(R, T, mode, tol);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(256), 0, c->stream, c->N, c->d_f, c->d_q, c->d_minv,
-                     c->d_r, c->d_p, c->d_part);
-  hipLaunchKernelGGL(k_cg_init_scalars, dim3(1), dim3(256), 0, c->stream, gv, c->d_part, c->d_scal,
-                     tol, c->d_flag);
-  FEA_HIP_CHECK(c, hipGetLastError());
-
   int flag = 0, it = 0;
   const int batch = 32;
   while (it < max_iter) {
     const int n = (max_iter - it < batch) ? (max_iter - it) : batch;
-    for (int k = 0; k < n; ++k) enqueue_cg_iteration(c, it + k);
+    for (int k = 0; k < n; ++k)
+      if ((rc = enq_cg_iteration(R, T, it + k))) return rc;
     it += n;
-    FEA_HIP_CHECK(c, hipGetLastError());
-    FEA_HIP_CHECK(c, hipMemcpyAsync(&flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    if (flag != 0) break;
+    (void)hipSetDevice(c0->device);
+    FEA_HIP_CHECK(c0, hipGetLastError());
+    FEA_HIP_CHECK(c0, hipMemcpyAsync(&flag, c0->d_flag, sizeof(int), hipMemcpyDeviceToHost, c0->stream));
+    FEA_HIP_CHECK(c0, hipStreamSynchronize(c0->stream));
+    if (flag != 0) break;           // every rank holds the same all-reduced sums, hence the same flag
   }
   double sc[5];
-  FEA_HIP_CHECK(c, hipMemcpy(sc, c->d_scal, sizeof(sc), hipMemcpyDeviceToHost));
+  FEA_HIP_CHECK(c0, hipMemcpyAsync(sc, c0->d_scal, sizeof(sc), hipMemcpyDeviceToHost, c0->stream));
+  FEA_HIP_CHECK(c0, hipStreamSynchronize(c0->stream));
   int done_it = it;
   if (flag == -1000000000) done_it = 0;
   else if (flag > 0) done_it = flag;
@@ -457,34 +617,74 @@ int solve_pcg(feahip_ctx *c, int type, double tol, int max_iter, int *iters, dou
   if (iters) *iters = done_it;
   if (resid) *resid = (sc[2] > 0) ? sqrt(sc[3] / sc[2]) : sqrt(sc[3]);
   // leave the flag clear so stand-alone SpMV launches are not skipped
-  FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
+  FOR_RANKS(c) {
+    FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
+  }
   if (flag < 0 && flag != -1000000000) {
-    c->err = "CG breakdown (NaN or zero curvature) at iteration " + std::to_string(-flag);
+    c0->err = "CG breakdown (NaN or zero curvature) at iteration " + std::to_string(-flag);
     return FEAHIP_ENOTCONVERGED;
+  }
+  return FEAHIP_OK;
+}
+
+int solve_pcg(feahip_ctx *c, int type, double tol, int max_iter, int *iters, double *resid)
+{
+  std::vector<feahip_ctx *> R(1, c);
+  return dist_solve_pcg(R, type, tol, max_iter, iters, resid);
+}
+
+// cdot(f, u) over all ranks (fea_solver.c:208-210)
+int dist_energy(std::vector<feahip_ctx *> &R, double *out)
+{
+  Transport *T = R[0]->tr;
+  int rc;
+  FOR_RANKS(c) {
+    const int g = vec_grid_range(3 * (own1(c) - own0(c)));
+    hipLaunchKernelGGL(k_dot_partial, dim3(g), dim3(256), 0, c->stream, 3 * own0(c), 3 * own1(c), c->d_f, c->d_u, c->d_part);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, g, 1, RB, c->d_part, c->d_scal + 8);
+    FEA_HIP_CHECK(c, hipGetLastError());
+  }
+  if (T && (rc = T->allreduce(R, 0, 1))) return rc;
+  feahip_ctx *c0 = R[0];
+  (void)hipSetDevice(c0->device);
+  FEA_HIP_CHECK(c0, hipMemcpyAsync(out, c0->d_scal + 8, sizeof(double), hipMemcpyDeviceToHost, c0->stream));
+  FEA_HIP_CHECK(c0, hipStreamSynchronize(c0->stream));
+  return FEAHIP_OK;
+}
+
+// solver_update_nodes_with_solution (fea_solver.c:1270-1279) on every rank:
+// owners' increments travel to the halo copies first, then x += u everywhere
+// (u is zero outside a rank's owned and halo nodes).
+int dist_update_nodes_with_solution(std::vector<feahip_ctx *> &R, const double *u_host)
+{
+  Transport *T = R[0]->tr;
+  int rc;
+  FOR_RANKS(c) {
+    c->state_valid = false;
+    if (u_host) FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_u, u_host, sizeof(double) * (size_t)c->ndof, hipMemcpyHostToDevice, c->stream));
+  }
+  if (T && !u_host && (rc = T->exchange(R, 1))) return rc;
+  FOR_RANKS(c) {
+    hipLaunchKernelGGL(k_nodes_add, dim3((c->ndof + 255) / 256), dim3(256), 0, c->stream, c->ndof, c->d_u, c->d_x);
+    FEA_HIP_CHECK(c, hipGetLastError());
   }
   return FEAHIP_OK;
 }
 
 int time_pcg_iteration(feahip_ctx *c, int warmup, int iters, double *avg_ms)
 {
-  // set up a well-defined state: u = f, r = p = f, unit preconditioner blocks
-  hipLaunchKernelGGL(k_precond_build, dim3((c->N + 255) / 256), dim3(256), 0, c->stream, c->N,
-                     c->d_rowptr, c->d_colidx, c->d_K, 1, c->d_minv);
-  FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_u, c->d_f, sizeof(double) * (size_t)c->ndof, hipMemcpyDeviceToDevice, c->stream));
-  int rc = launch_spmv(c, c->d_u, c->d_q);
+  std::vector<feahip_ctx *> R(1, c);
+  Transport *T = c->tr;
+  int rc = enq_cg_start(R, T, 1, 0.0);
   if (rc) return rc;
-  const int gv = vec_grid(c);
-  hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(256), 0, c->stream, c->N, c->d_f, c->d_q, c->d_minv,
-                     c->d_r, c->d_p, c->d_part);
-  hipLaunchKernelGGL(k_cg_init_scalars, dim3(1), dim3(256), 0, c->stream, gv, c->d_part, c->d_scal,
-                     0.0, c->d_flag);
   FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
   hipEvent_t e0, e1;
   FEA_HIP_CHECK(c, hipEventCreate(&e0));
   FEA_HIP_CHECK(c, hipEventCreate(&e1));
-  for (int k = 0; k < warmup; ++k) enqueue_cg_iteration(c, k);
+  for (int k = 0; k < warmup; ++k) if ((rc = enq_cg_iteration(R, T, k))) return rc;
   FEA_HIP_CHECK(c, hipEventRecord(e0, c->stream));
-  for (int k = 0; k < iters; ++k) enqueue_cg_iteration(c, warmup + k);
+  for (int k = 0; k < iters; ++k) if ((rc = enq_cg_iteration(R, T, warmup + k))) return rc;
   FEA_HIP_CHECK(c, hipEventRecord(e1, c->stream));
   FEA_HIP_CHECK(c, hipEventSynchronize(e1));
   float ms = 0;

@@ -48,7 +48,15 @@ void k_assemble_visit(VisitArgs A)
   if (A.dbg & 4) t0 = __builtin_amdgcn_s_memtime();
   // node lists have a fixed stride per chunk, so they are fetched together with
   // the descriptor (one dependent latency less); unused tail entries are 0
-  const int chunk = A.chunk0 + blockIdx.x;
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so
+  // workgroup b and b+8 share an L2.  Give each XCD a contiguous eighth of the
+  // chunks: neighbouring chunks then re-read each other's halo coordinates
+  // from the same L2 (placement is a speed matter only).
+  const int nwg = gridDim.x, per = (nwg + 7) >> 3;
+  int cidx = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (A.dbg & 8) cidx = blockIdx.x;
+  if (cidx >= A.nchunks) return;   // the grid is padded to a multiple of 8
+  const int chunk = A.chunk0 + cidx;
   const int vn0 = A.vnode[(size_t)chunk * FEA_VISIT_MAX_NODES + lane];
   const VisitDesc d = A.desc[chunk];
   const int nrows = d.r1 - d.r0;
@@ -165,7 +173,7 @@ void k_assemble_visit(VisitArgs A)
     __builtin_amdgcn_s_waitcnt(0);
     t4 = __builtin_amdgcn_s_memtime();
     if (lane == 0) {
-      unsigned long long *o = A.stamps + (size_t)blockIdx.x * 8;
+      unsigned long long *o = A.stamps + (size_t)cidx * 8;
       o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t4 - t3; o[4] = t4 - t0; o[5] = t0; o[6] = t4; o[7] = t5;
     }
   }
@@ -183,7 +191,7 @@ int launch_assemble_visit(feahip_ctx *c, bool doK, bool doF)
   if ((A.dbg & 4) && !d_stamps) (void)hipMalloc((void **)&d_stamps, sizeof(unsigned long long) * 8 * (size_t)c->nachunks);
   A.stamps = d_stamps;
   if (c->nachunks_local <= 0) return FEAHIP_OK;
-  const dim3 grid(c->nachunks_local), blk(64);
+  const dim3 grid((c->nachunks_local + 7) & ~7), blk(64);
   if (doK && doF) hipLaunchKernelGGL((k_assemble_visit<true, true>), grid, blk, 0, c->stream, A);
   else if (doK)   hipLaunchKernelGGL((k_assemble_visit<true, false>), grid, blk, 0, c->stream, A);
   else            hipLaunchKernelGGL((k_assemble_visit<false, true>), grid, blk, 0, c->stream, A);

@@ -55,6 +55,16 @@ ABI = {
     "feahip_spmv": [C.c_void_p, _dp, _dp],
     "feahip_set_assembly": [C.c_void_p, C.c_int],
     "feahip_set_row_shard": [C.c_void_p, C.c_int, C.c_int],
+    "feahip_comm_unique_id": [C.c_void_p, C.c_int],
+    "feahip_comm_init": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "feahip_owned_rows": [C.c_void_p, _ip, _ip],
+    "feahip_group_init": [C.POINTER(C.c_void_p), C.c_int],
+    "feahip_group_solve_slae": [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_double, C.c_int, _ip, _dp],
+    "feahip_group_energy": [C.POINTER(C.c_void_p), C.c_int, _dp],
+    "feahip_group_update_nodes_with_solution": [C.POINTER(C.c_void_p), C.c_int],
+    "feahip_group_solve": [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                           C.c_double, C.c_int, _dp, C.c_int, _ip, _ip],
+    "feahip_shard_plan": [C.c_int, C.c_int, C.c_int, _ip, C.c_int, C.c_int, _ip, _ip, _ip, _ip, _ip, _ip],
     "feahip_sync": [C.c_void_p],
     "feahip_time_kernel": [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp],
     "feahip_sizes": [C.c_void_p, C.POINTER(C.c_longlong)],
@@ -378,6 +388,16 @@ class FeaSolver:
     def set_row_shard(self, rank, nranks):
         self._chk(self._lib.feahip_set_row_shard(self._ctx, rank, nranks))
 
+    def owned_rows(self):
+        a, b = C.c_int(0), C.c_int(0)
+        self._chk(self._lib.feahip_owned_rows(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def comm_init(self, rank, nranks, unique_id):
+        """unique_id: the 128 bytes rank 0 obtained from comm_unique_id()."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._chk(self._lib.feahip_comm_init(self._ctx, rank, nranks, buf))
+
     def sync(self):
         self._chk(self._lib.feahip_sync(self._ctx))
 
@@ -391,3 +411,94 @@ class FeaSolver:
         self._chk(self._lib.feahip_sizes(self._ctx, o))
         keys = ["N", "E", "npe", "G", "nnzb", "nchunks", "aux_bytes", "max_rowlen"]
         return dict(zip(keys, [int(v) for v in o]))
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    n = load_library().feahip_comm_unique_id(buf, 128)
+    if n <= 0:
+        raise FeaHipError(f"feahip_comm_unique_id failed ({n})")
+    return bytes(buf.raw[:128])
+
+
+def shard_plan(deck, rank, nranks):
+    """Host-only halo plan of one rank: dict(row0,row1,peers,send,recv) with
+    per-peer node-id arrays."""
+    lib = load_library()
+    el = np.ascontiguousarray(deck.elements, dtype=np.int32)
+    counts = np.zeros(5, dtype=np.int32)
+    args = (len(deck.nodes), len(el), el.shape[1], _i(el), rank, nranks)
+    rc = lib.feahip_shard_plan(*args, _i(counts), None, None, None, None, None)
+    if rc != 0:
+        raise FeaHipError(f"feahip_shard_plan failed ({rc})")
+    npeer, nsend, nrecv = int(counts[0]), int(counts[1]), int(counts[2])
+    peers = np.zeros(max(npeer, 1), dtype=np.int32)
+    soff, roff = np.zeros(npeer + 1, dtype=np.int32), np.zeros(npeer + 1, dtype=np.int32)
+    sidx, ridx = np.zeros(max(nsend, 1), dtype=np.int32), np.zeros(max(nrecv, 1), dtype=np.int32)
+    rc = lib.feahip_shard_plan(*args, _i(counts), _i(peers), _i(soff), _i(roff), _i(sidx), _i(ridx))
+    if rc != 0:
+        raise FeaHipError(f"feahip_shard_plan failed ({rc})")
+    return {"row0": int(counts[3]), "row1": int(counts[4]), "peers": [int(p) for p in peers[:npeer]],
+            "send": [sidx[soff[k]:soff[k + 1]].copy() for k in range(npeer)],
+            "recv": [ridx[roff[k]:roff[k + 1]].copy() for k in range(npeer)]}
+
+
+class FeaGroup:
+    """n contexts of one mesh sharded by rows and driven from this process
+    (feahip_group_* entries)."""
+
+    def __init__(self, deck, n, device=0):
+        self.deck, self.n = deck, n
+        self.ranks = [FeaSolver(deck, device=device) for _ in range(n)]
+        self._lib = load_library()
+        self._arr = (C.c_void_p * n)(*[r._ctx for r in self.ranks])
+        self._chk(self._lib.feahip_group_init(self._arr, n))
+        self.rows = [r.owned_rows() for r in self.ranks]
+
+    def _chk(self, rc):
+        if rc != 0:
+            msgs = [self._lib.feahip_last_error(r._ctx).decode() for r in self.ranks]
+            raise FeaHipError(f"libfeahip group error {rc}: {msgs}")
+
+    def each(self, name, *args):
+        return [getattr(r, name)(*args) for r in self.ranks]
+
+    def solve_slae(self, solver_type, tolerance, max_iterations):
+        it, res = C.c_int(0), C.c_double(0)
+        self._chk(self._lib.feahip_group_solve_slae(self._arr, self.n, solver_type, tolerance, max_iterations,
+                                                    C.byref(it), C.byref(res)))
+        return it.value, res.value
+
+    def energy(self):
+        t = C.c_double(0)
+        self._chk(self._lib.feahip_group_energy(self._arr, self.n, C.byref(t)))
+        return t.value
+
+    def update_nodes_with_solution(self):
+        self._chk(self._lib.feahip_group_update_nodes_with_solution(self._arr, self.n))
+
+    def solve(self, load_increments, max_newton, modified_newton, desired_tolerance, solver_type,
+              solver_tolerance=1e-14, solver_max_iter=20000):
+        cap = load_increments * max_newton
+        tol_log = np.zeros(cap)
+        its = np.zeros(load_increments, dtype=np.int32)
+        done = C.c_int(0)
+        self._chk(self._lib.feahip_group_solve(self._arr, self.n, load_increments, max_newton, int(modified_newton),
+                                               desired_tolerance, solver_type, solver_tolerance, solver_max_iter,
+                                               _d(tol_log), cap, _i(its), C.byref(done)))
+        return done.value, its, tol_log[:int(its.sum())]
+
+    def gather(self, name):
+        """Owned rows of a per-node ([N][3]) or per-dof ([3N]) getter, stitched together."""
+        parts = self.each(name)
+        out = parts[0].copy()
+        for (a, b), p in zip(self.rows, parts):
+            if out.ndim == 2:
+                out[a:b] = p[a:b]
+            else:
+                out[3 * a:3 * b] = p[3 * a:3 * b]
+        return out
+
+    def close(self):
+        for r in self.ranks:
+            r.close()

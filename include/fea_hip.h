@@ -133,6 +133,45 @@ int feahip_solve(feahip_ctx *ctx, int load_increments, int max_newton,
                  double *tol_log, int tol_log_cap, int *its_log,
                  int *steps_done);
 
+/* ---- multi-GPU: row-sharded operation ---------------------------------- */
+/* The reference is one process; sharding is new.  Nodes (block rows of K,
+ * entries of f, u, x) are owned by one rank each, in contiguous ranges; a rank
+ * assembles every element touching its rows, so assembly needs no exchange.
+ * The linear solve exchanges halo rows (ncclSend/ncclRecv between slab
+ * neighbours) and all-reduces one to three doubles per CG step; the Newton
+ * test <u,f> is all-reduced so every rank takes the same branch.
+ *
+ * One process per GPU: rank 0 calls feahip_comm_unique_id (128 bytes),
+ * broadcasts it by any means (bench.py: torch.distributed), every rank calls
+ * feahip_comm_init; after that the ordinary entries above (create_stiffness,
+ * apply_prescribed_bc, solve_slae, energy, update_nodes_with_solution, solve)
+ * are collective over the ranks.  Every rank holds the whole mesh.          */
+int feahip_comm_unique_id(void *out, int cap);
+int feahip_comm_init(feahip_ctx *ctx, int rank, int nranks, const void *unique_id);
+/* nodes [row0, row1) are this rank's; getters are authoritative there only  */
+int feahip_owned_rows(feahip_ctx *ctx, int *row0, int *row1);
+
+/* In-process group: n contexts of the same mesh (on any devices) driven by one
+ * host thread; halo rows move by device copies, sums on the host.  Same
+ * kernels and halo plan as the RCCL path.                                    */
+int feahip_group_init(feahip_ctx **ctxs, int n);
+int feahip_group_solve_slae(feahip_ctx **ctxs, int n, int solver_type, double tolerance,
+                            int max_iterations, int *iters, double *resid);
+int feahip_group_energy(feahip_ctx **ctxs, int n, double *tolerance);
+int feahip_group_update_nodes_with_solution(feahip_ctx **ctxs, int n);
+int feahip_group_solve(feahip_ctx **ctxs, int n, int load_increments, int max_newton,
+                       int modified_newton, double desired_tolerance, int solver_type,
+                       double solver_tolerance, int solver_max_iter, double *tol_log,
+                       int tol_log_cap, int *its_log, int *steps_done);
+
+/* Host-only (no device): the halo plan of one rank from the element->node
+ * map.  First call with null lists fills counts[5] = {npeers, nsend, nrecv,
+ * row0, row1}; second call fills peers[npeers], send_off/recv_off[npeers+1],
+ * send_idx[nsend], recv_idx[nrecv] (node ids, ascending per peer).           */
+int feahip_shard_plan(int n_nodes, int n_elems, int npe, const int *elements, int rank,
+                      int nranks, int *counts, int *peers, int *send_off, int *recv_off,
+                      int *send_idx, int *recv_idx);
+
 /* ---- reference-shaped views -------------------------------------------- */
 
 int feahip_set_nodes(feahip_ctx *ctx, const double *nodes);   /* nodes_p    */

@@ -1,0 +1,101 @@
+"""The row-sharded solve on one MI355X: n contexts of the same mesh, each
+owning a slab of rows, driven by the in-process group transport (same kernels,
+same halo plan as the RCCL path; only the byte mover differs)."""
+import os
+
+import numpy as np
+import pytest
+
+import feahip
+import mesh
+from oracle_binding import OracleSolver
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    s = np.abs(b).max()
+    return np.abs(a - b).max() / (s if s > 0 else 1.0)
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_sharded_assembly_is_the_unsharded_one(n):
+    deck = mesh.bar_deck(dims=(3, 40, 3))
+    x = mesh.deformed_state(deck.nodes)
+    one = feahip.FeaSolver(deck)
+    one.set_nodes(x)
+    one.create_stiffness_and_residual()
+    off, idx, val = one.matrix_yale()
+    f = one.forces()
+    g = feahip.FeaGroup(deck, n)
+    g.each("set_nodes", x)
+    g.each("create_stiffness_and_residual")
+    seen = np.zeros(len(deck.nodes), dtype=int)
+    for (a, b), r in zip(g.rows, g.ranks):
+        seen[a:b] += 1
+        _, _, v = r.matrix_yale()
+        lo, hi = off[3 * a], off[3 * b]
+        assert np.array_equal(v[lo:hi], val[lo:hi])               # owned rows: same bits
+        assert np.all(v[:lo] == 0) and np.all(v[hi:] == 0)        # nothing else written
+        assert np.array_equal(r.forces()[3 * a:3 * b], f[3 * a:3 * b])
+    assert np.all(seen == 1)
+    g.close(); one.close()
+
+
+@pytest.mark.parametrize("n,solver", [(2, feahip.PCG_ILU), (3, feahip.CG)])
+def test_sharded_linear_solve(n, solver):
+    deck = mesh.bar_deck(dims=(3, 48, 3))
+    one = feahip.FeaSolver(deck)
+    one.update_nodes_with_bc(1.0); one.create_stiffness_and_residual(); one.apply_prescribed_bc(0.0)
+    it1, res1 = one.solve_slae(solver, 1e-15, 20000)
+    g = feahip.FeaGroup(deck, n)
+    g.each("update_nodes_with_bc", 1.0); g.each("create_stiffness_and_residual"); g.each("apply_prescribed_bc", 0.0)
+    itn, resn = g.solve_slae(solver, 1e-15, 20000)
+    assert resn < 1e-14 and abs(itn - it1) <= 2
+    assert rel(g.gather("solution"), one.solution()) < 1e-11
+    assert g.energy() == pytest.approx(one.energy(), rel=1e-11)
+    g.close(); one.close()
+
+
+def test_sharded_newton_matches_oracle(decks_dir):
+    """The shipped clamped deck on 2 ranks: same iteration sequence as the
+    oracle, displacements within 1e-10 (BASELINE.json)."""
+    deck = feahip.Deck.load(os.path.join(decks_dir, "neohook_brick.sexp"))
+    o = OracleSolver(deck)
+    od, oits, otol = o.solve(1, deck.max_newton_count, True, deck.desired_tolerance, feahip.CHOLESKY)
+    g = feahip.FeaGroup(deck, 2)
+    gd, gits, gtol = g.solve(1, deck.max_newton_count, True, deck.desired_tolerance, feahip.CHOLESKY)
+    assert gd == od == 1 and list(gits) == list(oits) == [13]
+    assert np.abs(gtol - otol).max() < 1e-10 * np.abs(otol).max()
+    assert rel(g.gather("nodes") - deck.nodes, o.nodes() - deck.nodes) < 1e-10
+    g.close()
+
+
+def test_sharded_full_newton_patch_test():
+    from test_oracle_closed_form import nh_closed_form
+    deck = mesh.bar_deck(dims=(3, 30, 3), recipe="uniaxial", dy=0.05)
+    g = feahip.FeaGroup(deck, 3)
+    done, its, tol = g.solve(1, 8, False, 1e-22, feahip.PCG_ILU, 1e-15)
+    k1 = 1 + 0.05 / 6
+    k2, syy = nh_closed_form(k1)
+    A = deck.nodes.min(axis=0)
+    expect = A + (deck.nodes - A) * np.array([k2, k1, k2])
+    assert np.abs(g.gather("nodes") - expect).max() < 1e-11
+    g.close()
+
+
+def test_rccl_single_rank_comm():
+    """RCCL transport with one rank (all this box can host): unique id,
+    communicator, all-reduce of the CG scalars, empty halo exchange."""
+    deck = mesh.bar_deck(dims=(2, 12, 2))
+    s = feahip.FeaSolver(deck)
+    s.comm_init(0, 1, feahip.comm_unique_id())
+    assert s.owned_rows() == (0, len(deck.nodes))
+    s.update_nodes_with_bc(1.0); s.create_stiffness_and_residual(); s.apply_prescribed_bc(0.0)
+    it, res = s.solve_slae(feahip.PCG_ILU, 1e-14, 5000)
+    ref = feahip.FeaSolver(deck)
+    ref.update_nodes_with_bc(1.0); ref.create_stiffness_and_residual(); ref.apply_prescribed_bc(0.0)
+    it2, _ = ref.solve_slae(feahip.PCG_ILU, 1e-14, 5000)
+    assert it == it2 and rel(s.solution(), ref.solution()) < 1e-13
+    assert s.energy() == pytest.approx(ref.energy(), rel=1e-13)
+    s.close(); ref.close()

@@ -11,16 +11,18 @@ cd /tmp && export TMPDIR=/tmp
 PASSES=(
  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM"
  "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES"
- "TA_BUSY_avr TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
- "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum"
- "FETCH_SIZE GRBM_GUI_ACTIVE"
+ "FETCH_SIZE"
  "WRITE_SIZE"
- "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"
+ "TCC_HIT_sum TCC_MISS_sum"
+ "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"
+ "GRBM_GUI_ACTIVE"
 )
 i=0
 NP=${PMC_PASSES:-99}
+FIRST=${PMC_FIRST:-1}
 for P in "${PASSES[@]}"; do
   [ $i -ge $NP ] && break
+  if [ $((i+1)) -lt $FIRST ]; then i=$((i+1)); continue; fi
   i=$((i+1))
   timeout -k 10 240 rocprofv3 --pmc $P --output-format csv -d "$OUT/pass$i" -- python3 "$ROOTDIR/bench.py" --no-newton --cpu-sample 0 --steps 3 --warmup 1 "$@" > "$OUT/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$OUT/pass$i.log"; exit 1; }
   echo "pass $i done"
