@@ -19,6 +19,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -39,6 +40,19 @@ def algorithmic_bytes(npe, E, N, nnz):
 
 def spmv_bytes(nnz, N):
     return 8 * nnz + 4 * nnz // 9 + 4 * (N + 1) + 48 * N
+
+
+def pmc_traffic(args, world):
+    """HBM bytes per assembly launch from rocprofv3 PMC counters (FETCH_SIZE + WRITE_SIZE, separate passes,
+    tools/pmc_profile.sh).  bench.py cannot collect PMC itself: the number is the one measured for the
+    default configuration this round (profiles/), and null for any other configuration."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if world != 1 or args.n != 66 or args.quadratic or args.model != "neohookean" or not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))["assembly_bytes_per_launch"]
+    except Exception:                               # noqa: BLE001
+        return None
 
 
 def cpu_baseline(n_sample, seconds_cap=40.0):
@@ -102,8 +116,21 @@ def main():
     deck = mesh.bar_deck(n=args.n, quadratic=args.quadratic, recipe="clamped", model=model,
                          solver_type=feahip.PCG_ILU, solver_tolerance=1e-14, solver_max_iter=20000)
     solver = feahip.FeaSolver(deck, device=local)
+    comm_ok = False
     if world > 1:
-        solver.set_row_shard(rank, world)
+        # RCCL communicator for the sharded linear solve (halo rows + scalar all-reduces).  The timed
+        # assembly below needs no collective; if the communicator cannot be built it still runs.
+        uid = [feahip.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        try:
+            solver.comm_init(rank, world, uid[0])
+            comm_ok = True
+        except Exception as e:                      # noqa: BLE001
+            print(f"[rank {rank}] RCCL communicator unavailable ({e}); assembly-only sharding", file=sys.stderr)
+            solver.set_row_shard(rank, world)
+        flags = [None] * world
+        dist.all_gather_object(flags, comm_ok)
+        comm_ok = all(flags)
     solver.set_nodes(mesh.deformed_state(deck.nodes))
     sz = solver.sizes()
     t_setup = time.perf_counter() - t_setup
@@ -124,62 +151,86 @@ def main():
     ms_per_step = 1e3 * dt / args.steps
     value = E_total * args.steps / dt
 
-    out = None
-    if rank == 0:
-        # dominant kernel, HIP events on the library's own stream
-        k_ms = solver.time_kernel(0, warmup=2, iters=max(5, args.steps))
-        share = 1.0 / world
-        B = algorithmic_bytes(sz["npe"], E_total, N, nnz) * share
-        achieved = B / (k_ms * 1e-3) / 1e9
-        spmv_ms = solver.time_kernel(3, warmup=2, iters=10)
-        pcg_ms = solver.time_kernel(4, warmup=2, iters=10)
-        extras = {
-            "assembly_kernel_ms": k_ms,
-            "residual_only_ms": solver.time_kernel(2, warmup=2, iters=10),
-            "spmv_ms": spmv_ms,
-            "spmv_GBps": spmv_bytes(nnz, N) * share / (spmv_ms * 1e-3) / 1e9,
-            "pcg_iteration_ms": pcg_ms,
-            "setup_s": t_setup,
-            "aux_map_bytes_per_element": sz["aux_bytes"] / E_total,
-        }
-        if not args.no_newton and world == 1:
-            # one full Newton iteration of the first load increment: bump, assemble, BC, PCG to 1e-14, update
-            solver.set_nodes(deck.nodes)
-            solver.sync()
-            tn = time.perf_counter()
-            solver.update_nodes_with_bc(1.0)
-            solver.create_stiffness_and_residual()
-            solver.apply_prescribed_bc(0.0)
-            its, res = solver.solve_slae(feahip.PCG_ILU, 1e-14, 20000)
-            en = solver.energy()
-            solver.update_nodes_with_solution()
-            solver.sync()
-            tn = time.perf_counter() - tn
-            extras.update({"newton_iters_per_s": 1.0 / tn, "newton_iteration_s": tn, "cg_iterations": its,
-                           "cg_relative_residual": res, "energy_u_f": en})
-        out = {
-            "metric": "element-stiffness assemblies/sec", "value": value, "unit": "elements/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"{E_total} {'TET10/5GP' if args.quadratic else 'TET4/1GP'} {args.model} block "
-                                   f"({args.n}x{6 * args.n}x{args.n} Kuhn cubes on the 1x6x1 bar), "
-                                   f"stiffness+residual assembly, deformed state k1=1.1",
-                       "elements": E_total, "nodes": N, "scalar_nnz": nnz,
-                       "sharding": f"block rows in {world} slab(s) across y"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_assemble_visit" if not args.quadratic else "k_assemble_rowowner", "algorithmic_bytes_per_launch": B},
-            "extras": extras,
-        }
-        if args.cpu_sample > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+    share = 1.0 / world
+    # dominant kernel, HIP events on the library's own stream (local, no collective)
+    k_ms = solver.time_kernel(0, warmup=2, iters=max(5, args.steps))
+    B = algorithmic_bytes(sz["npe"], E_total, N, nnz) * share
+    achieved = B / (k_ms * 1e-3) / 1e9
+    spmv_ms = solver.time_kernel(3, warmup=2, iters=10)
+    extras = {
+        "assembly_kernel_ms": k_ms,
+        "residual_only_ms": solver.time_kernel(2, warmup=2, iters=10),
+        "spmv_ms": spmv_ms,
+        "spmv_GBps": spmv_bytes(nnz, N) * share / (spmv_ms * 1e-3) / 1e9,
+        "setup_s": t_setup,
+        "aux_map_bytes_per_element": sz["aux_bytes"] / E_total,
+        "rccl_sharded_solve": comm_ok if world > 1 else None,
+    }
+    out = {
+        "metric": "element-stiffness assemblies/sec", "value": value, "unit": "elements/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{E_total} {'TET10/5GP' if args.quadratic else 'TET4/1GP'} {args.model} block "
+                               f"({args.n}x{6 * args.n}x{args.n} Kuhn cubes on the 1x6x1 bar), "
+                               f"stiffness+residual assembly, deformed state k1=1.1",
+                   "elements": E_total, "nodes": N, "scalar_nnz": nnz,
+                   "sharding": f"block rows in {world} slab(s) across y, ghost elements recomputed, "
+                               f"no collective in assembly"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, world),
+                     "kernel": "k_assemble_visit" if not args.quadratic else "k_assemble_rowowner",
+                     "algorithmic_bytes_per_launch": B},
+        "extras": extras,
+    }
+
+    printed = threading.Event()
+
+    def emit():
+        if rank == 0 and not printed.is_set():
+            printed.set()
+            print(json.dumps(out), flush=True)
+
+    # The sharded solve is a bonus leg: a watchdog prints the line and leaves if a collective wedges.
+    def bail():
+        extras["solve_leg"] = "timed out"
+        emit()
+        os._exit(0)
+
+    watchdog = threading.Timer(240.0, bail)
+    watchdog.daemon = True
+    if world == 1 or comm_ok:
+        watchdog.start()
+        try:
+            extras["pcg_iteration_ms"] = solver.time_kernel(4, warmup=2, iters=10)      # collective when sharded
+            if not args.no_newton:
+                # one full Newton iteration of the first load increment: bump, assemble, BC, PCG to 1e-14, update
+                solver.set_nodes(deck.nodes)
+                solver.sync(); barrier()
+                tn = time.perf_counter()
+                solver.update_nodes_with_bc(1.0)
+                solver.create_stiffness_and_residual()
+                solver.apply_prescribed_bc(0.0)
+                its, res = solver.solve_slae(feahip.PCG_ILU, 1e-14, 20000)
+                en = solver.energy()
+                solver.update_nodes_with_solution()
+                solver.sync(); barrier()
+                tn = time.perf_counter() - tn
+                extras.update({"newton_iters_per_s": 1.0 / tn, "newton_iteration_s": tn, "cg_iterations": its,
+                               "cg_relative_residual": res, "energy_u_f": en})
+        except Exception as e:                      # noqa: BLE001
+            extras["solve_leg"] = f"failed: {e}"
+        watchdog.cancel()
+    if rank == 0 and args.cpu_sample > 0 and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+    emit()
     solver.close()
-    barrier()
-    if rank == 0:
-        print(json.dumps(out))
     if world > 1:
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:                           # noqa: BLE001
+            pass
 
 
 if __name__ == "__main__":
