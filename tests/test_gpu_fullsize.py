@@ -1,0 +1,100 @@
+"""BASELINE.json sizes (configs[1] = 1M linear tets, configs[2] = 10M) checked
+through size-independent properties -- the oracle would need minutes there:
+K symmetric, K.(rigid translation) = 0 before BCs, stress-free reference
+state, residual = -K.u consistency, the uniaxial closed form as the exact FE
+answer (patch test), sharded = unsharded."""
+import numpy as np
+import pytest
+
+import feahip
+import mesh
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def block_1m():
+    deck = mesh.bar_deck(n=31, recipe="clamped")          # 1 072 476 TET4, 191 488 nodes
+    s = feahip.FeaSolver(deck)
+    yield deck, s
+    s.close()
+
+
+def test_1m_counts_and_reference_state(block_1m):
+    deck, s = block_1m
+    assert len(deck.elements) == 1072476 and len(deck.nodes) == 191488
+    s.set_nodes(deck.nodes)
+    s.create_residual_forces()
+    assert np.abs(s.forces()).max() < 1e-11
+    assert s.update_state() == 0
+
+
+def test_1m_stiffness_properties(block_1m):
+    deck, s = block_1m
+    s.set_nodes(mesh.deformed_state(deck.nodes))
+    s.create_stiffness_and_residual()
+    rng = np.random.default_rng(5)
+    scale = None
+    for ax in range(3):
+        t = np.zeros(s.ndof); t[ax::3] = 1.0
+        y = s.spmv(t)
+        if scale is None:
+            scale = np.abs(s.spmv(rng.normal(size=s.ndof))).max()
+        assert np.abs(y).max() < 1e-11 * scale                     # translation-free
+    a, b = rng.normal(size=s.ndof), rng.normal(size=s.ndof)
+    assert abs(a @ s.spmv(b) - b @ s.spmv(a)) < 1e-11 * abs(a @ s.spmv(b))   # symmetric
+    # the three strategies agree at this size too
+    f0 = s.forces()
+    ya = s.spmv(a)
+    for strat in (feahip.ASM_ROWOWNER, feahip.ASM_PATCH):
+        s.set_assembly(strat)
+        s.create_stiffness_and_residual()
+        assert np.abs(s.spmv(a) - ya).max() < 1e-12 * np.abs(ya).max()
+        assert np.abs(s.forces() - f0).max() < 1e-12 * np.abs(f0).max()
+    s.set_assembly(feahip.ASM_AUTO)
+
+
+def test_1m_uniaxial_patch_test_closed_form():
+    """config 2 recipe: prescribed-displacement uniaxial tension; the closed form of
+    exact-solutions/uniaxial/uniaxial_neohookean_bonet.m is the exact FE answer."""
+    from test_oracle_closed_form import nh_closed_form
+    deck = mesh.bar_deck(n=31, recipe="uniaxial")
+    dy = mesh.increment_for(31)
+    s = feahip.FeaSolver(deck)
+    done, its, tol = s.solve(load_increments=1, max_newton=8, modified_newton=False, desired_tolerance=1e-22,
+                             solver_type=feahip.PCG_ILU, solver_tolerance=1e-15, solver_max_iter=40000)
+    assert done == 1 or its[0] == 8
+    k1 = 1 + dy / 6
+    k2, syy = nh_closed_form(k1)
+    A = deck.nodes.min(axis=0)
+    expect = A + (deck.nodes - A) * np.array([k2, k1, k2])
+    assert np.abs(s.nodes() - expect).max() < 2e-11
+    S = s.stresses()
+    assert np.abs(S[:, 0, 1, 1] - syy).max() < 1e-8
+    s.close()
+
+
+def test_10m_assembly_properties():
+    """configs[2]: the headline mesh.  One assembly, checked by K.t = 0,
+    symmetry and f = 0 at the reference state."""
+    deck = mesh.bar_deck(n=66, recipe="clamped")
+    assert len(deck.elements) == 10349856 and len(deck.nodes) == 1782133
+    s = feahip.FeaSolver(deck)
+    s.create_residual_forces()
+    assert np.abs(s.forces()).max() < 1e-10
+    s.set_nodes(mesh.deformed_state(deck.nodes))
+    s.create_stiffness_and_residual()
+    assert s.update_state() == 0
+    rng = np.random.default_rng(9)
+    a, b = rng.normal(size=s.ndof), rng.normal(size=s.ndof)
+    yb = s.spmv(b)
+    t = np.zeros(s.ndof); t[1::3] = 1.0
+    assert np.abs(s.spmv(t)).max() < 1e-11 * np.abs(yb).max()
+    assert abs(a @ yb - b @ s.spmv(a)) < 1e-11 * abs(a @ yb)
+    # sharded = unsharded on the owned rows (spot check of one rank of 8)
+    ya = s.spmv(a)
+    s.set_row_shard(3, 8)
+    r0, r1 = s.owned_rows()
+    s.create_stiffness_and_residual()
+    assert np.array_equal(s.spmv(a)[3 * r0:3 * r1], ya[3 * r0:3 * r1])
+    s.close()
