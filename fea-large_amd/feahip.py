@@ -109,6 +109,25 @@ class FeaDeck(C.Structure):
     ]
 
 
+class StepSnapshot(C.Structure):
+    """struct fea_step_snapshot of host/fea_host.h."""
+    _fields_ = [("nodes", _dp), ("stress0", _dp)]
+
+
+def export_gmsh(path, deck, nodes_steps, stress0_steps):
+    """fea_export_gmsh: nodes_steps[k] is [N][3], stress0_steps[k] is [E][3][3] after load step k+1."""
+    h = load_host_library()
+    n = len(nodes_steps)
+    keep = [(np.ascontiguousarray(a, dtype=np.float64), np.ascontiguousarray(b, dtype=np.float64))
+            for a, b in zip(nodes_steps, stress0_steps)]
+    arr = (StepSnapshot * max(n, 1))()
+    for k, (a, b) in enumerate(keep):
+        arr[k].nodes, arr[k].stress0 = _d(a), _d(b)
+    fd = deck.to_struct()
+    if h.fea_export_gmsh(os.fsencode(path), C.byref(fd), arr, n) != 0:
+        raise FeaHipError(f"could not write {path}")
+
+
 def load_host_library():
     global _host
     if _host is None:
@@ -128,6 +147,10 @@ def load_host_library():
         h.fea_deck_create_solver.restype = C.c_int
         h.fea_solve.argtypes = [C.POINTER(FeaDeck), C.c_void_p, C.c_void_p, _dp, C.c_int]
         h.fea_solve.restype = C.c_int
+        h.fea_export_gmsh.argtypes = [C.c_char_p, C.POINTER(FeaDeck), C.POINTER(StepSnapshot), C.c_int]
+        h.fea_export_gmsh.restype = C.c_int
+        h.fea_export_name.argtypes = [C.c_char_p, C.c_char_p]
+        h.fea_export_name.restype = None
         _host = h
     return _host
 

@@ -77,6 +77,31 @@ int fea_deck_create_solver(const fea_deck *deck, int device, feahip_ctx **ctx,
 int fea_solve(const fea_deck *deck, feahip_ctx *ctx, void *log /* FILE* */,
               double *x_steps, int x_steps_cap);
 
+/* Per-load-step snapshot (load_step of the reference, fea_solver.h:212-224):
+ * node coordinates and the stress of Gauss point 0 of every element.         */
+typedef struct fea_step_snapshot {
+  double *nodes;      /* [nodes_count][3] */
+  double *stress0;    /* [elements_count][9], stresses[e][0] */
+} fea_step_snapshot;
+
+/* fea_solve with snapshots for the exporter: steps[cap] are allocated by the
+ * callee (free with fea_snapshots_free).  Returns completed steps or <0.     */
+int fea_solve_with_snapshots(const fea_deck *deck, feahip_ctx *ctx, void *log,
+                             fea_step_snapshot *steps, int cap);
+void fea_snapshots_free(fea_step_snapshot *steps, int n);
+
+/* solver_export_tetrahedra10_gmsh (fea_solver.c:1375-1488): Gmsh 2.0 ASCII,
+ * nodes with %f, TET10 elements with local nodes 8 and 9 swapped, and per
+ * load step (step 0 = zeros) NodeData "Displacements" and ElementData
+ * "Stress tensor" (Gauss point 0) tagged load*0.83333333.  4-node elements
+ * are written as Gmsh type 4.                                                */
+int fea_export_gmsh(const char *filename, const fea_deck *deck,
+                    const fea_step_snapshot *steps, int nsteps);
+
+/* "<base>.msh" next to the deck, as initial_data_load builds it
+ * (fea_solver.c:1681-1687); out must hold strlen(deck_path)+5 bytes.        */
+void fea_export_name(const char *deck_path, char *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -315,3 +315,28 @@ def test_inverted_elements_are_reported():
     s.create_stiffness()
     assert s.update_state() > 0
     s.close()
+
+
+def test_feasolver_hip_command_line(decks_dir, tmp_path):
+    """`feasolver_hip deck.sexp` = the reference's command line: loads the deck,
+    logs the convergence lines of fea_solver.c:212-224, writes <base>.msh."""
+    import re
+    import subprocess
+    src = open(os.path.join(decks_dir, "neohook_brick.sexp")).read()
+    deckfile = tmp_path / "two_steps.sexp"
+    deckfile.write_text(src.replace(":load-increments-count 120", ":load-increments-count 2"))
+    exe = os.path.join(os.path.dirname(feahip.LIB_PATH), "feasolver_hip")
+    res = subprocess.run([exe, str(deckfile)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    out = res.stdout
+    assert out.count("Newton iteration") == 25 and "Load increment 2 finished" in out      # 13 + 12
+    tol = [float(v) for v in re.findall(r"Tolerance <X,R> = (\S+)", out)]
+    assert tol[0] == pytest.approx(5.392131, rel=1e-6) and abs(tol[12]) < 1e-6 <= abs(tol[11])
+    msh = (tmp_path / "two_steps.msh").read_text().splitlines()
+    assert msh.count("$NodeData") == 3 and msh.count("$ElementData") == 3
+    # displacement of a top-face node after two increments: 2 x 0.05 along y
+    deck = feahip.Deck.load(str(deckfile))
+    top = int(deck.presc_node[deck.presc_values[:, 1] != 0][0])
+    last = [i for i, l in enumerate(msh) if l == "$NodeData"][-1]
+    row = msh[last + 9 + top].split()
+    assert int(row[0]) == top + 1 and float(row[2]) == pytest.approx(0.1, abs=1e-6)

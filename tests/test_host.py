@@ -184,3 +184,33 @@ def test_product_does_not_reach_into_the_oracle():
                 assert "oracle" not in txt.lower().replace("oracle/ (", ""), os.path.join(dirpath, fn)
     out = os.popen(f"ldd {feahip.LIB_PATH} {feahip.HOST_LIB_PATH}").read()
     assert "liboracle" not in out and "libfearef" not in out
+
+
+def test_gmsh_export_format(tmp_path):
+    """Layout of solver_export_tetrahedra10_gmsh (fea_solver.c:1375-1488)."""
+    deck = mesh.bar_deck(dims=(1, 1, 1), quadratic=True)
+    N, E = len(deck.nodes), len(deck.elements)
+    x1 = deck.nodes + np.array([0.0, 0.25, 0.0])
+    s1 = np.tile(np.arange(9.0).reshape(3, 3), (E, 1, 1))
+    p = tmp_path / "out.msh"
+    feahip.export_gmsh(str(p), deck, [x1], [s1])
+    lines = p.read_text().splitlines()
+    assert lines[:3] == ["$MeshFormat", "2.0 0 8", "$EndMeshFormat"]
+    assert lines[3] == "$Nodes" and int(lines[4]) == N
+    assert lines[5] == "1 %f %f %f" % tuple(deck.nodes[0])
+    ie = lines.index("$Elements")
+    assert int(lines[ie + 1]) == E
+    first = lines[ie + 2].split()
+    assert first[:6] == ["1", "11", "3", "1", "1", "1"]            # Gmsh type 11 = 10-node tetrahedron
+    ours = deck.elements[0] + 1
+    assert [int(v) for v in first[6:]] == list(ours[:8]) + [ours[9], ours[8]]      # nodes 8 <-> 9 (:1431-1434)
+    nd = [i for i, l in enumerate(lines) if l == "$NodeData"]
+    ed = [i for i, l in enumerate(lines) if l == "$ElementData"]
+    assert len(nd) == 2 and len(ed) == 2                            # load 0 (zeros) and load 1
+    assert lines[nd[0] + 4] == "%f" % 0.0 and lines[nd[1] + 4] == "%f" % 0.83333333    # time tag (:1447)
+    assert lines[nd[0] + 9] == "1 0.000000 0.000000 0.000000"
+    assert lines[nd[1] + 9] == "1 0.000000 0.250000 0.000000"
+    assert lines[ed[1] + 9].split()[:4] == ["1", "0.000000", "1.000000", "2.000000"]
+    buf = C.create_string_buffer(64)
+    feahip.load_host_library().fea_export_name(b"dir.d/neohook_brick.sexp", buf)
+    assert buf.value == b"dir.d/neohook_brick.msh"
