@@ -12,6 +12,7 @@
  * rule uses the 8-digit literals of fea_solver.c:33-47 on purpose.
  * TETRAHEDRA4 (1 point) is a build extension for the BASELINE.json
  * linear-tet configurations: corner shape functions, centroid rule.
+ * The 27-point rule is a build extension for BASELINE.json config 5.
  */
 #include <string.h>
 #include "fea_host.h"
@@ -65,11 +66,33 @@ static double t4_N(int i, double r, double s, double t)
 
 static double t4_dN(int i, int d) { return i == 0 ? -1 : (i - 1 == d ? 1 : 0); }
 
+
+/* 27-point rule (3 x 3 x 3 Gauss-Legendre on the unit cube collapsed onto the
+ * tetrahedron: r = u, s = v(1-u), t = w(1-u)(1-v), Jacobian (1-u)^2 (1-v)).
+ * Not in the reference (it stops at 5 points, fea_solver.c:1495-1504);
+ * BASELINE.json config 5 asks for it.  Weights sum to 1/6 like the
+ * reference's rules ("divisor 6 already taken into account", :26-28).       */
+static void rule27_host(double rule[27][4])
+{
+  static const double gx[3] = {0.5 - 0.38729833462074170, 0.5, 0.5 + 0.38729833462074170};   /* (1 -+ sqrt(3/5))/2 */
+  static const double gw[3] = {5. / 18., 8. / 18., 5. / 18.};
+  int a, b, c, n = 0;
+  for (a = 0; a < 3; ++a)
+    for (b = 0; b < 3; ++b)
+      for (c = 0; c < 3; ++c, ++n) {
+        const double u = gx[a], v = gx[b], w = gx[c];
+        rule[n][0] = gw[a] * gw[b] * gw[c] * (1 - u) * (1 - u) * (1 - v);
+        rule[n][1] = u;
+        rule[n][2] = v * (1 - u);
+        rule[n][3] = w * (1 - u) * (1 - v);
+      }
+}
+
 int fea_element_tables(int ele_type, int G, double *weights, double *forms, double *dforms)
 {
   /* {weight (divisor 6 inside), r, s, t} */
   static const double a = 0.58541020, b = 0.13819660;
-  double rule[5][4];
+  double rule[27][4];
   int npe, g, i, d;
   if (ele_type == FEA_TETRAHEDRA10) npe = 10;
   else if (ele_type == FEA_TETRAHEDRA4) npe = 4;
@@ -86,6 +109,8 @@ int fea_element_tables(int ele_type, int G, double *weights, double *forms, doub
       rule[g][0] = (9 / 20.) / 6.;
       rule[g][1] = g == 1 ? 1 / 2. : 1 / 6.; rule[g][2] = g == 2 ? 1 / 2. : 1 / 6.; rule[g][3] = g == 3 ? 1 / 2. : 1 / 6.;
     }
+  } else if (G == 27) {
+    rule27_host(rule);
   } else if (G == 1 && ele_type == FEA_TETRAHEDRA4) {
     rule[0][0] = 1 / 6.; rule[0][1] = rule[0][2] = rule[0][3] = 1 / 4.;
   } else

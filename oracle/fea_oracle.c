@@ -274,6 +274,28 @@ static double tet4_dform(int i, int d, double r, double s, double t)
   return (i - 1 == d) ? 1 : 0;
 }
 
+
+/* 27-point rule (3 x 3 x 3 Gauss-Legendre on the unit cube collapsed onto the
+ * tetrahedron: r = u, s = v(1-u), t = w(1-u)(1-v), Jacobian (1-u)^2 (1-v)).
+ * Not in the reference (it stops at 5 points, fea_solver.c:1495-1504);
+ * BASELINE.json config 5 asks for it.  Weights sum to 1/6 like the
+ * reference's rules ("divisor 6 already taken into account", :26-28).       */
+static void rule27_orc(double rule[27][4])
+{
+  static const double gx[3] = {0.5 - 0.38729833462074170, 0.5, 0.5 + 0.38729833462074170};   /* (1 -+ sqrt(3/5))/2 */
+  static const double gw[3] = {5. / 18., 8. / 18., 5. / 18.};
+  int a, b, c, n = 0;
+  for (a = 0; a < 3; ++a)
+    for (b = 0; b < 3; ++b)
+      for (c = 0; c < 3; ++c, ++n) {
+        const double u = gx[a], v = gx[b], w = gx[c];
+        rule[n][0] = gw[a] * gw[b] * gw[c] * (1 - u) * (1 - u) * (1 - v);
+        rule[n][1] = u;
+        rule[n][2] = v * (1 - u);
+        rule[n][3] = w * (1 - u) * (1 - v);
+      }
+}
+
 int orc_elem_table_init(orc_elem_table *tb, int kind, int ngauss)
 {
   /* {weight, r, s, t}; the 8-digit literals are the reference's own
@@ -288,6 +310,7 @@ int orc_elem_table_init(orc_elem_table *tb, int kind, int ngauss)
                      {(9 / 20.) / 6., 1 / 6., 1 / 6., 1 / 2.},
                      {(9 / 20.) / 6., 1 / 6., 1 / 6., 1 / 6.}};
   double g1[1][4] = {{1 / 6., 1 / 4., 1 / 4., 1 / 4.}};
+  double g27[27][4];
   double (*gd)[4];
   int g, i, j;
   memset(tb, 0, sizeof(*tb));
@@ -295,6 +318,7 @@ int orc_elem_table_init(orc_elem_table *tb, int kind, int ngauss)
     tb->npe = 10;
     if (ngauss == 4) gd = g4;
     else if (ngauss == 5) gd = g5;
+    else if (ngauss == 27) { rule27_orc(g27); gd = g27; }   /* extension */
     else return -1;           /* fea_solver.c:1495-1504 */
   } else if (kind == ORC_TET4) {
     tb->npe = 4;

@@ -78,6 +78,15 @@ def test_tet10_reference_deck_assembly(decks_dir, name):
     s.close()
 
 
+def test_tet10_27_point_rule():
+    """BASELINE.json config 5's rule (27 Gauss points per quadratic tet)."""
+    deck = mesh.bar_deck(dims=(2, 3, 2), quadratic=True, gauss=27)
+    s, o = make_pair(deck, mesh.deformed_state(deck.nodes, k1=1.06, wiggle=3e-3))
+    check_assembly(s, o, strategies=(feahip.ASM_ROWOWNER, feahip.ASM_ATOMIC))
+    assert rel(s.stresses(), o.stresses()) < 1e-11
+    s.close()
+
+
 def test_tet10_four_point_rule(decks_dir):
     deck = feahip.Deck.load(os.path.join(decks_dir, "neohook_brick.sexp"))
     deck.gauss_nodes_count = 4

@@ -11,7 +11,7 @@ import oracle_binding as ob
 from oracle_binding import OracleSolver
 
 
-@pytest.mark.parametrize("kind,G", [(ob.TET10, 4), (ob.TET10, 5), (ob.TET4, 1)])
+@pytest.mark.parametrize("kind,G", [(ob.TET10, 4), (ob.TET10, 5), (ob.TET10, 27), (ob.TET4, 1)])
 def test_gauss_tables(kind, G):
     w, forms, dforms = ob.elem_table(kind, G)
     assert w.sum() == pytest.approx(1.0 / 6.0, abs=1e-16)          # fea_solver.c:32-54
@@ -23,6 +23,26 @@ def test_four_point_rule_uses_the_reference_literals():
     w, forms, dforms = ob.elem_table(ob.TET10, 4)
     a, b = 0.58541020, 0.13819660                                  # fea_solver.c:33-35
     assert dforms[0, 0, 1] == 4 * a - 1 and dforms[0, 1, 2] == 4 * b - 1
+
+
+def test_27_point_rule_integrates_cubics():
+    """config 5's rule: exact for total degree 3 on the unit tetrahedron
+    (int r^a s^b t^c = a! b! c! / (a+b+c+3)!)."""
+    from math import factorial as f
+    L = ob.lib()
+    t = ob.ElemTable()
+    assert L.orc_elem_table_init(t, ob.TET10, 27) == 0
+    # recover the points from the linear parts of the corner shape functions: N1+N4/2+N5/2+N8/2 = r etc.
+    w, forms, _ = ob.elem_table(ob.TET10, 27)
+    r = forms[:, 1] + 0.5 * (forms[:, 4] + forms[:, 5] + forms[:, 8])
+    s = forms[:, 2] + 0.5 * (forms[:, 5] + forms[:, 6] + forms[:, 9])
+    tt = forms[:, 3] + 0.5 * (forms[:, 7] + forms[:, 8] + forms[:, 9])
+    assert (r > 0).all() and (s > 0).all() and (tt > 0).all() and (r + s + tt < 1).all()
+    for a in range(4):
+        for b in range(4 - a):
+            for c in range(4 - a - b):
+                exact = f(a) * f(b) * f(c) / f(a + b + c + 3)
+                assert (w * r ** a * s ** b * tt ** c).sum() == pytest.approx(exact, rel=1e-13)
 
 
 def test_unsupported_rule_rejected():
