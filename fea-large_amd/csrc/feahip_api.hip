@@ -127,7 +127,7 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
       c->visit_bytes = (long long)(hv.desc.size() * sizeof(VisitDesc) + hv.vnode.size() * 4 + hv.vrec.size() * 4);
     }
   }
-  if ((rc = dev_zeros(c, &c->d_K, (size_t)c->nnzb * 9))) return rc;
+  if ((rc = dev_zeros(c, &c->d_K, (size_t)c->nnzb * 9 + 2))) return rc;   // +2: the SpMV reads aligned 80-byte windows
   if ((rc = dev_zeros(c, &c->d_f, (size_t)c->ndof))) return rc;
   if ((rc = dev_zeros(c, &c->d_u, (size_t)c->ndof))) return rc;
   if ((rc = dev_zeros(c, &c->d_r, (size_t)c->ndof))) return rc;

@@ -52,12 +52,18 @@ void k_assemble_rowowner(AsmArgs A)
     const uint32_t w = A.inc[p];
     const int e = (int)(w & 0x0FFFFFFFu), la = (int)(w >> 28);
     int nd[NPE];
-    double xe[NPE][3], Xe[NPE][3];
+    double xe[NPE == 4 ? 4 : 1][3], Xe[NPE == 4 ? 4 : 1][3];
     // NPE == 4: the element is presented with its local nodes renumbered
     // k -> k XOR la (an even permutation: orientation and every tensor stay
     // what they are), so the row node is always local node 0 and nothing
     // below needs a per-lane select on doubles.
-    load_element<NPE>(A, e, nd, xe, Xe, NPE == 4 ? la : 0);
+    // NPE == 10: only the node ids are kept; the coordinates are streamed
+    // from L1 inside every Gauss point's sums (gp_state_stream).
+    if constexpr (NPE == 4) load_element<4>(A, e, nd, xe, Xe, la);
+    else {
+#pragma unroll
+      for (int k = 0; k < NPE; ++k) nd[k] = A.conn[(size_t)e * NPE + k];
+    }
     int a = nd[0];
     if constexpr (NPE != 4) {
 #pragma unroll
@@ -77,7 +83,8 @@ void k_assemble_rowowner(AsmArgs A)
     double fa[3] = {0, 0, 0};
     for (int gp = 0; gp < A.G; ++gp) {
       GPState<NPE> s;
-      gp_state<NPE, LINTET, false>(xe, Xe, A.tab, gp, A.model, A.lambda, A.mu, s);
+      if constexpr (NPE == 4) gp_state<4, LINTET, false>(xe, Xe, A.tab, gp, A.model, A.lambda, A.mu, s);
+      else gp_state_stream<NPE>(A.x, A.X0, nd, A.tab, gp, A.model, A.lambda, A.mu, s);
       if (!(s.detJ > 0.0) && DOK && la == 0) atomicAdd(A.bad, 1);
       if (s.detJ == 0.0) continue;      // reference keeps no gradient then (fea_solver.c:697)
       double ga[3] = {s.g[0][0], s.g[0][1], s.g[0][2]};
