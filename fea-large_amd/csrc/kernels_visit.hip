@@ -40,7 +40,7 @@ void k_assemble_visit(VisitArgs A)
 {
   __shared__ double sC[FEA_VISIT_MAX_NODES * 6];       // x, X0 of the chunk's nodes
   __shared__ double sK[DOK ? FEA_ACHUNK_BLOCKS * 9 + 2 : 2];
-  __shared__ double sF[FEA_CHUNK_ROWS * 3];
+  __shared__ double sF[4][FEA_CHUNK_ROWS * 3 + 3];        // 4 replicas (a row's visits spread over them), padded off the same banks
   __shared__ int sRow[FEA_CHUNK_ROWS + 1];             // first block of every row, relative to b0
   __shared__ int sDiag[FEA_CHUNK_ROWS];
   const int lane = threadIdx.x;
@@ -81,7 +81,7 @@ void k_assemble_visit(VisitArgs A)
   if (DOK)
     for (int t = lane; t < d.nb * 9; t += 64) sKt[t] = 0.0;
   if (DOF)
-    for (int t = lane; t < nrows * 3; t += 64) sF[t] = 0.0;
+    for (int t = lane; t < 4 * (FEA_CHUNK_ROWS * 3 + 3); t += 64) (&sF[0][0])[t] = 0.0;
   __syncthreads();
   if (A.dbg & 4) t1 = __builtin_amdgcn_s_memtime();
 
@@ -102,7 +102,9 @@ void k_assemble_visit(VisitArgs A)
       }
       GPState<4> s;
       gp_state<4, true, false>(xe, Xe, A.tab, 0, A.model, A.lambda, A.mu, s);
-      if (!(s.detJ > 0.0) && DOK) {                     // rare: count it from its lowest-numbered node only
+      // the host may have renumbered the element with an odd permutation (bit 0 of sl):
+      // the sign of det J is then the opposite of the stored element's
+      if (!(((sl & 1u) ? -s.detJ : s.detJ) > 0.0) && DOK) {   // rare: count it from its lowest-numbered node only
         const int *gn = A.vnode + (size_t)chunk * FEA_VISIT_MAX_NODES;
         const int g0 = gn[n0];
         if (g0 < gn[n1] && g0 < gn[n2] && g0 < gn[n3]) atomicAdd(A.bad, 1);
@@ -113,7 +115,7 @@ void k_assemble_visit(VisitArgs A)
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             const double v = -s.vol * (s.sig[i][0] * ga[0] + s.sig[i][1] * ga[1] + s.sig[i][2] * ga[2]);
-            __hip_atomic_fetch_add(sF + n0 * 3 + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&sF[lane & 3][n0 * 3 + i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
         }
         if (DOK) {
@@ -167,7 +169,7 @@ void k_assemble_visit(VisitArgs A)
   }
   if (DOF) {
     double *fd = A.f + (size_t)d.r0 * 3;
-    for (int t = lane; t < nrows * 3; t += 64) fd[t] = sF[t];
+    for (int t = lane; t < nrows * 3; t += 64) fd[t] = (sF[0][t] + sF[1][t]) + (sF[2][t] + sF[3][t]);
   }
   if (A.dbg & 4) {
     __builtin_amdgcn_s_waitcnt(0);

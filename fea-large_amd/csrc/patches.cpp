@@ -14,6 +14,7 @@
 // Diagonal blocks have no entries: they are minus the sum of their row.
 #include "feahip_internal.h"
 #include <algorithm>
+#include <cstdlib>
 #include <thread>
 
 namespace {
@@ -145,9 +146,10 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
   out.vrec.assign((size_t)E * 4 * 2, 0);
   out.vnode.assign((size_t)np * FEA_VISIT_MAX_NODES, 0);
   std::vector<char> bad((size_t)np, 0);
+  const char *ord = getenv("FEAHIP_VISIT_ORDER");
+  const bool interleave_rows = !(ord && ord[0] == '1');
   par_for(np, [&](int lo, int hi) {
     std::vector<int> halo;
-    std::vector<uint32_t> vis;
     for (int p = lo; p < hi; ++p) {
       const int r0 = hp.achunk[p], r1 = hp.achunk[p + 1];
       const int p0 = hp.incptr[r0], p1 = hp.incptr[r1];
@@ -177,26 +179,95 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
         if (g >= r0 && g < r1) return g - r0;
         return nown + (int)(std::lower_bound(halo.begin(), halo.end(), g) - halo.begin());
       };
-      // visits dealt round-robin over the rows: the lanes of one pass then work
-      // on as many different rows as the chunk has (few same-address LDS adds)
-      vis.clear();
-      int maxlen = 0;
-      for (int r = r0; r < r1; ++r) maxlen = std::max(maxlen, hp.incptr[r + 1] - hp.incptr[r]);
-      for (int k = 0; k < maxlen; ++k)
-        for (int r = r0; r < r1; ++r)
-          if (k < hp.incptr[r + 1] - hp.incptr[r]) vis.push_back(hp.inc_rows[hp.incptr[r] + k]);
-      for (int v = 0; v < (int)vis.size(); ++v) {
-        const int e = (int)(vis[v] & 0x0FFFFFFFu), la = (int)(vis[v] >> 28);
-        const int a = conn[(size_t)e * 4 + la];
-        const int *cb = hp.colidx.data() + hp.rowptr[a], *ce = hp.colidx.data() + hp.rowptr[a + 1];
-        uint32_t ids = 0, sl = 0;
-        for (int k = 0; k < 4; ++k) {
-          const int g = conn[(size_t)e * 4 + (k ^ la)];                 // row node first
-          ids |= (uint32_t)lid(g) << (8 * k);
-          if (k) sl |= (uint32_t)(std::lower_bound(cb, ce, g) - cb) << (8 * k);
+      // Schedule of the chunk's visits.  A pass of the kernel = 64 visits, each
+      // adding its three off-diagonal blocks in three steps; lanes that add to
+      // the same (row, column) block in the same step serialise in the LDS
+      // (~11 clk per extra lane).  So (1) the visits of every row are split
+      // over the passes keeping each column's count per pass low, and (2) each
+      // visit's three column nodes are ordered so that, step by step, the
+      // visits of one row in one pass hit different columns (greedy
+      // edge-colouring of the visit x column graph).
+      const int nrounds = (d.nvisit + 63) / 64;
+      struct V { uint32_t w; int row; int slot[3]; int node[3]; int round; int order[3]; };
+      std::vector<V> vs;
+      vs.reserve((size_t)d.nvisit);
+      for (int r = r0; r < r1; ++r)
+        for (int q = hp.incptr[r]; q < hp.incptr[r + 1]; ++q) {
+          V v; v.w = hp.inc_rows[q]; v.row = r - r0; v.round = 0;
+          const int e = (int)(v.w & 0x0FFFFFFFu), la = (int)(v.w >> 28);
+          const int *cb = hp.colidx.data() + hp.rowptr[r], *ce = hp.colidx.data() + hp.rowptr[r + 1];
+          int m = 0;
+          for (int k = 0; k < 4; ++k) {
+            if (k == la) continue;
+            v.node[m] = k;                                                   // local index in the stored element
+            v.slot[m] = (int)(std::lower_bound(cb, ce, conn[(size_t)e * 4 + k]) - cb);
+            ++m;
+          }
+          v.order[0] = 0; v.order[1] = 1; v.order[2] = 2;
+          vs.push_back(v);
         }
-        out.vrec[(size_t)(p0 + v) * 2] = ids;
-        out.vrec[(size_t)(p0 + v) * 2 + 1] = sl;
+      // (1) pass of every visit
+      std::vector<int> rsize((size_t)nrounds, 0);
+      std::vector<uint8_t> deg((size_t)nrounds * nown * 256, 0);
+      auto D = [&](int rd, int row, int slot) -> uint8_t & { return deg[((size_t)rd * nown + row) * 256 + slot]; };
+      const int cap = (d.nvisit + nrounds - 1) / nrounds;
+      for (auto &v : vs) {
+        int best = -1, bestcost = 1 << 30;
+        for (int rd = 0; rd < nrounds; ++rd) {
+          if (rsize[rd] >= std::min(64, cap)) continue;
+          int mx = 0;
+          for (int m = 0; m < 3; ++m) mx = std::max(mx, (int)D(rd, v.row, v.slot[m]));
+          const int cost = mx * 1024 + rsize[rd];
+          if (cost < bestcost) { bestcost = cost; best = rd; }
+        }
+        if (best < 0) best = (int)(std::min_element(rsize.begin(), rsize.end()) - rsize.begin());
+        v.round = best; rsize[best]++;
+        for (int m = 0; m < 3; ++m) D(best, v.row, v.slot[m])++;
+      }
+      // (2) step of every column inside its visit
+      static const int perms[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {2, 1, 0}, {1, 0, 2}};
+      std::vector<uint8_t> used((size_t)nrounds * nown * 3 * 256, 0);
+      auto U = [&](int rd, int row, int step, int slot) -> uint8_t & { return used[(((size_t)rd * nown + row) * 3 + step) * 256 + slot]; };
+      for (auto &v : vs) {
+        int bestp = 0, bestc = 1 << 30;
+        for (int pi = 0; pi < 6; ++pi) {
+          int cst = 0;
+          for (int st = 0; st < 3; ++st) cst += U(v.round, v.row, st, v.slot[perms[pi][st]]);
+          if (cst < bestc) { bestc = cst; bestp = pi; }
+        }
+        for (int st = 0; st < 3; ++st) { v.order[st] = perms[bestp][st]; U(v.round, v.row, st, v.slot[v.order[st]])++; }
+      }
+      // emit pass by pass
+      std::stable_sort(vs.begin(), vs.end(), [](const V &x, const V &y) { return x.round < y.round; });
+      if (interleave_rows) {
+        // inside a pass, deal the visits round-robin over the rows
+        std::vector<V> tmp2; tmp2.reserve(vs.size());
+        size_t b = 0;
+        while (b < vs.size()) {
+          size_t e2 = b;
+          while (e2 < vs.size() && vs[e2].round == vs[b].round) ++e2;
+          std::vector<std::vector<V>> per((size_t)nown);
+          for (size_t i = b; i < e2; ++i) per[(size_t)vs[i].row].push_back(vs[i]);
+          for (size_t k = 0;; ++k) {
+            bool any = false;
+            for (auto &pr : per) if (k < pr.size()) { tmp2.push_back(pr[k]); any = true; }
+            if (!any) break;
+          }
+          b = e2;
+        }
+        vs.swap(tmp2);
+      }
+      for (int i = 0; i < (int)vs.size(); ++i) {
+        const V &v = vs[i];
+        const int e = (int)(v.w & 0x0FFFFFFFu), la = (int)(v.w >> 28);
+        int perm[4] = {la, v.node[v.order[0]], v.node[v.order[1]], v.node[v.order[2]]};
+        int inv = 0;                                     // parity of the renumbering (orientation flips when odd)
+        for (int x = 0; x < 4; ++x) for (int y = x + 1; y < 4; ++y) inv += perm[x] > perm[y];
+        uint32_t ids = 0, sl = (uint32_t)(inv & 1);
+        for (int k = 0; k < 4; ++k) ids |= (uint32_t)lid(conn[(size_t)e * 4 + perm[k]]) << (8 * k);   // row node first
+        for (int k = 1; k < 4; ++k) sl |= (uint32_t)v.slot[v.order[k - 1]] << (8 * k);
+        out.vrec[(size_t)(p0 + i) * 2] = ids;
+        out.vrec[(size_t)(p0 + i) * 2 + 1] = sl;
       }
     }
   });
