@@ -111,20 +111,19 @@ void k_assemble_visit(VisitArgs A)
       }
       if (s.detJ != 0.0) {                               // fea_solver.c:697: no gradient otherwise
         const double ga[3] = {s.g[0][0], s.g[0][1], s.g[0][2]};
+        RowVecs rv;
+        row_vectors(ga, s.sig, s.l1, s.m1, s.vol, rv);
         if (DOF && !(A.dbg & 2)) {
 #pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            const double v = -s.vol * (s.sig[i][0] * ga[0] + s.sig[i][1] * ga[1] + s.sig[i][2] * ga[2]);
-            __hip_atomic_fetch_add(&sF[lane & 3][n0 * 3 + i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
+          for (int i = 0; i < 3; ++i)
+            __hip_atomic_fetch_add(&sF[lane & 3][n0 * 3 + i], -rv.s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (DOK) {
           const int rowoff = sRow[n0] * 9;               // row node first: n0 is the row, chunk-local
 #pragma unroll
           for (int k = 1; k < 4; ++k) {                  // the diagonal block comes from the row sum
-            double h[3], m[3], t[3], blk[9];
-            col_vectors(s.g[k], s.sig, s.l1, s.m1, s.vol, h, m, t);
-            block_ab(ga, h, m, t, blk);
+            double blk[9];
+            block_row(rv, s.g[k], blk);
             double *dst = sKt + rowoff + (int)((sl >> (8 * k)) & 255u) * 9;
             if (A.dbg & 1) dst = sKt + lane * 9;
 #pragma unroll
