@@ -125,6 +125,14 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
       if ((rc = dev_upload(c, &c->d_vrec, hv.vrec.data(), hv.vrec.size()))) return rc;
       c->have_visits = true;
       c->visit_bytes = (long long)(hv.desc.size() * sizeof(VisitDesc) + hv.vnode.size() * 4 + hv.vrec.size() * 4);
+      HostPairs pr;
+      build_host_pairs(elements, hp, hv, pr);
+      if (pr.ok) {
+        if ((rc = dev_upload(c, &c->d_pairdesc, pr.desc.data(), pr.desc.size()))) return rc;
+        if ((rc = dev_upload(c, &c->d_prec, pr.prec.data(), pr.prec.size()))) return rc;
+        c->have_pairs = true;
+        c->pair_bytes = (long long)(pr.desc.size() * sizeof(VisitDesc) + hv.vnode.size() * 4 + pr.prec.size() * 4);
+      }
     }
   }
   if ((rc = dev_zeros(c, &c->d_K, (size_t)c->nnzb * 9 + 2))) return rc;   // +2: the SpMV reads aligned 80-byte windows
@@ -189,7 +197,7 @@ extern "C" void feahip_destroy(feahip_ctx *c)
 {
   if (!c) return;
   void *ptrs[] = {c->d_table, c->d_conn, c->d_X0, c->d_x, c->d_rowptr, c->d_colidx, c->d_K, c->d_Kstash,
-                  c->d_incptr, c->d_inc, c->d_incslot, c->d_chunk, c->d_diag, c->d_pdesc, c->d_pnode, c->d_pelem, c->d_pent, c->d_pbptr, c->d_vdesc, c->d_vnode, c->d_vrec, c->d_f, c->d_u, c->d_r, c->d_p,
+                  c->d_incptr, c->d_inc, c->d_incslot, c->d_chunk, c->d_diag, c->d_pdesc, c->d_pnode, c->d_pelem, c->d_pent, c->d_pbptr, c->d_vdesc, c->d_vnode, c->d_vrec, c->d_pairdesc, c->d_prec, c->d_f, c->d_u, c->d_r, c->d_p,
                   c->d_q, c->d_minv, c->d_part, c->d_scal, c->d_flag, c->d_cdof, c->d_cval,
                   c->d_dofmask, c->d_F, c->d_S};
   for (void *p : ptrs)
@@ -215,7 +223,7 @@ extern "C" int feahip_sync(feahip_ctx *c)
 extern "C" int feahip_set_assembly(feahip_ctx *c, int strategy)
 {
   CTX_GUARD(c);
-  if (strategy < FEAHIP_ASM_AUTO || strategy > FEAHIP_ASM_STAGED) { c->err = "unknown assembly strategy"; return FEAHIP_EINVAL; }
+  if (strategy < FEAHIP_ASM_AUTO || strategy > FEAHIP_ASM_PAIRED) { c->err = "unknown assembly strategy"; return FEAHIP_EINVAL; }
   c->strategy = strategy;
   return FEAHIP_OK;
 }
@@ -575,6 +583,7 @@ extern "C" int feahip_sizes(feahip_ctx *c, long long *o)
   if (!c || !o) return FEAHIP_EINVAL;
   o[0] = c->N; o[1] = c->E; o[2] = c->npe; o[3] = c->G; o[4] = c->nnzb; o[5] = c->nchunks;
   // bytes of the maps the default assembly kernel reads besides the algorithmic inputs
-  o[6] = c->have_visits ? c->visit_bytes + (long long)(c->N + 1) * 8 : c->aux_bytes; o[7] = c->max_rowlen;
+  o[6] = c->have_visits ? c->visit_bytes + (long long)(c->N + 1) * 8 : c->aux_bytes;
+  o[7] = c->max_rowlen;
   return FEAHIP_OK;
 }

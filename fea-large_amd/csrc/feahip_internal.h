@@ -83,6 +83,10 @@ struct feahip_ctx {
   int *d_vnode = nullptr;
   uint32_t *d_vrec = nullptr;
   long long visit_bytes = 0;
+  bool have_pairs = false;
+  struct VisitDesc *d_pairdesc = nullptr;
+  uint32_t *d_prec = nullptr;
+  long long pair_bytes = 0;
   // vectors (3N doubles)
   double *d_f = nullptr, *d_u = nullptr;
   double *d_r = nullptr, *d_p = nullptr, *d_q = nullptr, *d_minv = nullptr;
@@ -174,6 +178,14 @@ struct HostVisits {
   bool ok = false;
 };
 void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, HostVisits &out);
+struct HostPairs {
+  std::vector<VisitDesc> desc;       // visit_off / nvisit = first pair / pairs of the chunk
+  std::vector<uint32_t> prec;        // [4 * pairs]: ids a,p,q,r | s,flags | slots p,q,r,s | 0
+  long long npairs_total = 0;
+  bool ok = false;
+};
+void build_host_pairs(const int *conn, const HostPattern &hp, const HostVisits &hv, HostPairs &out);
+int launch_assemble_pair(feahip_ctx *c, bool doK, bool doF);
 int launch_assemble_visit(feahip_ctx *c, bool doK, bool doF);
 
 // launchers (kernels_assemble.hip / kernels_patch.hip / kernels_solve.hip)

@@ -298,6 +298,14 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
   // PATCH is the bitwise-reproducible variant, slower today
   if (strat == FEAHIP_ASM_AUTO)
     strat = c->have_visits ? FEAHIP_ASM_STAGED : (rowowner_ok ? FEAHIP_ASM_ROWOWNER : FEAHIP_ASM_ATOMIC);
+  if (strat == FEAHIP_ASM_PAIRED) {
+    if (!c->have_pairs) {
+      c->err = "paired assembly needs linear tetrahedra whose chunks fit the LDS tiles";
+      return FEAHIP_EINVAL;
+    }
+    if (doK) FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));
+    return launch_assemble_pair(c, doK, doF);
+  }
   if (strat == FEAHIP_ASM_STAGED) {
     if (!c->have_visits) {
       c->err = "staged assembly needs linear tetrahedra whose chunks fit the LDS tiles";

@@ -49,8 +49,12 @@ enum {
   FEAHIP_ASM_PATCH = 3,    /* linear tets: element states shared through LDS,
                               block owners gather; no atomics, bitwise
                               reproducible                                   */
-  FEAHIP_ASM_STAGED = 4    /* linear tets: row-owner visits with node
+  FEAHIP_ASM_STAGED = 4,   /* linear tets: row-owner visits with node
                               coordinates and connectivity staged in LDS     */
+  FEAHIP_ASM_PAIRED = 5    /* STAGED with two face-sharing elements per lane:
+                              shared blocks summed in registers (fewer LDS
+                              operations; measured 5 % slower than STAGED
+                              for K+f, 8 % faster for f alone)               */
 };
 
 /* ---- lifetime ----------------------------------------------------------- */
