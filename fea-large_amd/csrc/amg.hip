@@ -1,0 +1,352 @@
+// amg.hip -- device side of the aggregation multigrid preconditioner (amg.h).
+#include "amg.h"
+#include <cmath>
+#include <cstdlib>
+
+// from kernels_solve.hip
+void enq_spmv_arrays(hipStream_t stream, int nchunks, const int *chunk, const int *rowptr, const int *colidx,
+                     const double *K, const double *xv, double *yv);
+void enq_cg_update_plain(feahip_ctx *c, int it);
+void enq_cg_direction_from(feahip_ctx *c, int it, const double *z);
+void enq_dot_rz(feahip_ctx *c, const double *r, const double *z);
+void enq_cg_init_plain(feahip_ctx *c);
+void enq_cg_init_scalars_plain(feahip_ctx *c, double tol);
+void enq_spmv_pq(feahip_ctx *c);
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+
+// coarse block = sum of its fine blocks, in list order (deterministic).  On
+// level 0 the prescribed dofs are left out of the coarse space (their rows of
+// the prolongator are zero): entries in a masked row or column are skipped.
+__global__ void k_galerkin(int nnzc, const int *cbptr, const int *cblist, const double *Kf, double *Kc,
+                           const int *cbrow, const int *colidx_f, const uint8_t *mask)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnzc) return;
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int p = cbptr[k]; p < cbptr[k + 1]; ++p) {
+    const int q = cblist[p];
+    const double *b = Kf + (size_t)q * 9;
+    if (mask) {
+      const int i = cbrow[q], j = colidx_f[q];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb)
+          if (!mask[3 * i + a] && !mask[3 * j + bb]) acc[3 * a + bb] += b[3 * a + bb];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] += b[t];
+    }
+  }
+  double *o = Kc + (size_t)k * 9;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) o[t] = acc[t];
+}
+
+// inverse of the diagonal 3x3 blocks; a singular block (aggregate made of
+// prescribed dofs only) gets the identity
+__global__ void k_block_inverse(int N, const int *diag, const double *K, double *minv)
+{
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= N) return;
+  double d[9];
+  for (int t = 0; t < 9; ++t) d[t] = K[(size_t)diag[a] * 9 + t];
+  // rows/columns that are entirely zero (masked dofs on the coarse levels) become identity rows
+  for (int i = 0; i < 3; ++i)
+    if (d[3 * i + i] == 0.0) d[3 * i + i] = 1.0;
+  const double det = d[0] * (d[4] * d[8] - d[5] * d[7]) - d[1] * (d[3] * d[8] - d[5] * d[6]) + d[2] * (d[3] * d[7] - d[4] * d[6]);
+  double m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (det != 0.0 && det == det) {
+    const double id = 1.0 / det;
+    m[0] = (d[4] * d[8] - d[5] * d[7]) * id; m[1] = (d[2] * d[7] - d[1] * d[8]) * id; m[2] = (d[1] * d[5] - d[2] * d[4]) * id;
+    m[3] = (d[5] * d[6] - d[3] * d[8]) * id; m[4] = (d[0] * d[8] - d[2] * d[6]) * id; m[5] = (d[2] * d[3] - d[0] * d[5]) * id;
+    m[6] = (d[3] * d[7] - d[4] * d[6]) * id; m[7] = (d[1] * d[6] - d[0] * d[7]) * id; m[8] = (d[0] * d[4] - d[1] * d[3]) * id;
+  }
+  for (int t = 0; t < 9; ++t) minv[(size_t)a * 9 + t] = m[t];
+}
+
+// x = omega D^-1 r                       (first smoothing sweep from x = 0)
+__global__ void k_smooth_first(int N, double omega, const double *minv, const double *r, double *x)
+{
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= N) return;
+  const double *m = minv + (size_t)a * 9;
+  const double r0 = r[(size_t)a * 3], r1 = r[(size_t)a * 3 + 1], r2 = r[(size_t)a * 3 + 2];
+  for (int i = 0; i < 3; ++i) x[(size_t)a * 3 + i] = omega * (m[3 * i] * r0 + m[3 * i + 1] * r1 + m[3 * i + 2] * r2);
+}
+
+// x += omega D^-1 (r - y)                (y = K x)
+__global__ void k_smooth_next(int N, double omega, const double *minv, const double *r, const double *y, double *x)
+{
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= N) return;
+  const double *m = minv + (size_t)a * 9;
+  const double t0 = r[(size_t)a * 3] - y[(size_t)a * 3], t1 = r[(size_t)a * 3 + 1] - y[(size_t)a * 3 + 1],
+               t2 = r[(size_t)a * 3 + 2] - y[(size_t)a * 3 + 2];
+  for (int i = 0; i < 3; ++i) x[(size_t)a * 3 + i] += omega * (m[3 * i] * t0 + m[3 * i + 1] * t1 + m[3 * i + 2] * t2);
+}
+
+// r_c[I] = sum_{i in I} (r[i] - y[i])     (P' (r - K x)), nodes in list order
+__global__ void k_restrict(int Nc, const int *aptr, const int *anodes, const double *r, const double *y,
+                           const uint8_t *mask, double *rc)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Nc * 3) return;
+  const int I = t / 3, d = t % 3;
+  double acc = 0;
+  for (int p = aptr[I]; p < aptr[I + 1]; ++p) {
+    const size_t k = (size_t)anodes[p] * 3 + d;
+    if (!mask || !mask[k]) acc += r[k] - y[k];
+  }
+  rc[t] = acc;
+}
+
+// x[i] += x_c[agg(i)]                      (P x_c)
+__global__ void k_prolong(int N, const int *agg, const double *xc, const uint8_t *mask, double over, double *x)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * 3) return;
+  if (mask && mask[t]) return;
+  x[t] += over * xc[(size_t)agg[t / 3] * 3 + t % 3];
+}
+
+// power iteration helpers for lambda_max(D^-1 K)
+__global__ void k_apply_minv(int N, const double *minv, const double *y, double *v)
+{
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= N) return;
+  const double *m = minv + (size_t)a * 9;
+  const double y0 = y[(size_t)a * 3], y1 = y[(size_t)a * 3 + 1], y2 = y[(size_t)a * 3 + 2];
+  for (int i = 0; i < 3; ++i) v[(size_t)a * 3 + i] = m[3 * i] * y0 + m[3 * i + 1] * y1 + m[3 * i + 2] * y2;
+}
+__global__ void k_fill_pattern(int n, double *v)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) v[t] = 1.0 + 0.37 * (double)((t * 2654435761u) >> 24) / 256.0;      // fixed pseudo-random start
+}
+__global__ void k_norm2_serial(int n, const double *v, double *out)
+{
+  // one block, fixed order: deterministic
+  __shared__ double s[256];
+  double a = 0;
+  for (int i = threadIdx.x; i < n; i += 256) a += v[i] * v[i];
+  s[threadIdx.x] = a;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w]; __syncthreads(); }
+  if (threadIdx.x == 0) out[0] = s[0];
+}
+__global__ void k_scale(int n, double f, double *v)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) v[t] *= f;
+}
+
+// ---------------------------------------------------------------------------
+// hierarchy
+// ---------------------------------------------------------------------------
+static AmgHierarchy *H(feahip_ctx *c) { return reinterpret_cast<AmgHierarchy *>(c->amg); }
+
+template <class T>
+static int up(feahip_ctx *c, T **dst, const std::vector<T> &v, long long &bytes)
+{
+  FEA_HIP_CHECK(c, hipMalloc((void **)dst, sizeof(T) * (v.size() ? v.size() : 1)));
+  if (!v.empty()) FEA_HIP_CHECK(c, hipMemcpy(*dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+  bytes += (long long)(sizeof(T) * v.size());
+  return FEAHIP_OK;
+}
+static int zeros(feahip_ctx *c, double **dst, size_t n, long long &bytes)
+{
+  FEA_HIP_CHECK(c, hipMalloc((void **)dst, sizeof(double) * (n ? n : 1)));
+  FEA_HIP_CHECK(c, hipMemset(*dst, 0, sizeof(double) * (n ? n : 1)));
+  bytes += (long long)(sizeof(double) * n);
+  return FEAHIP_OK;
+}
+
+int amg_create(feahip_ctx *c)
+{
+  if (c->amg) return FEAHIP_OK;
+  std::vector<HostAmgLevel> hl;
+  if (!build_host_amg(c->h_rowptr, c->h_colidx, hl)) {
+    c->err = "multigrid hierarchy unavailable for this mesh (too small, or a coarse row exceeds the SpMV chunk)";
+    return FEAHIP_EINVAL;
+  }
+  AmgHierarchy *h = new AmgHierarchy();
+  c->amg = h;
+  { const char *e = getenv("FEAHIP_AMG_GAMMA"); if (e) h->gamma = atoi(e); }
+  { const char *e = getenv("FEAHIP_AMG_OVER"); if (e) h->over = atof(e); }
+  { const char *e = getenv("FEAHIP_AMG_SWEEPS"); if (e) h->coarse_sweeps = atoi(e); }
+  int rc;
+  h->lv.resize(hl.size());
+  for (size_t l = 0; l < hl.size(); ++l) {
+    AmgLevel &L = h->lv[l];
+    const HostAmgLevel &S = hl[l];
+    L.N = S.N; L.nnzb = (int)S.colidx.size(); L.nchunks = (int)S.chunk.size() - 1; L.Nc = S.Nc;
+    if (l == 0) {
+      L.rowptr = c->d_rowptr; L.colidx = c->d_colidx; L.diag = c->d_diag; L.chunk = c->d_chunk; L.K = c->d_K;
+      L.nchunks = c->nchunks;
+    } else {
+      L.owns_matrix = true;
+      if ((rc = up(c, &L.rowptr, S.rowptr, h->bytes))) return rc;
+      if ((rc = up(c, &L.colidx, S.colidx, h->bytes))) return rc;
+      if ((rc = up(c, &L.diag, S.diag, h->bytes))) return rc;
+      if ((rc = up(c, &L.chunk, S.chunk, h->bytes))) return rc;
+      if ((rc = zeros(c, &L.K, (size_t)L.nnzb * 9, h->bytes))) return rc;
+      if ((rc = zeros(c, &L.r, (size_t)L.N * 3, h->bytes))) return rc;
+      if ((rc = zeros(c, &L.x, (size_t)L.N * 3, h->bytes))) return rc;
+      if ((rc = zeros(c, &L.y, (size_t)L.N * 3, h->bytes))) return rc;
+    }
+    if ((rc = zeros(c, &L.minv, (size_t)L.N * 9, h->bytes))) return rc;
+    if (S.Nc > 0) {
+      if ((rc = up(c, &L.agg, S.agg, h->bytes))) return rc;
+      if ((rc = up(c, &L.aptr, S.aptr, h->bytes))) return rc;
+      if ((rc = up(c, &L.anodes, S.anodes, h->bytes))) return rc;
+      if ((rc = up(c, &L.cbptr, S.cbptr, h->bytes))) return rc;
+      if ((rc = up(c, &L.cblist, S.cblist, h->bytes))) return rc;
+      if (l == 0 && (rc = up(c, &L.cbrow, S.cbrow, h->bytes))) return rc;
+    }
+  }
+  if ((rc = zeros(c, &h->d_z, (size_t)c->ndof, h->bytes))) return rc;
+  if ((rc = zeros(c, &h->d_pw, (size_t)c->ndof, h->bytes))) return rc;
+  return FEAHIP_OK;
+}
+
+void amg_destroy(feahip_ctx *c)
+{
+  AmgHierarchy *h = H(c);
+  if (!h) return;
+  for (AmgLevel &L : h->lv) {
+    void *own[] = {L.minv, L.agg, L.aptr, L.anodes, L.cbptr, L.cblist, L.cbrow, L.r, L.x, L.y};
+    for (void *p : own) if (p) (void)hipFree(p);
+    if (L.owns_matrix) { void *m[] = {L.rowptr, L.colidx, L.diag, L.chunk, L.K}; for (void *p : m) if (p) (void)hipFree(p); }
+  }
+  if (h->d_z) (void)hipFree(h->d_z);
+  if (h->d_pw) (void)hipFree(h->d_pw);
+  delete h;
+  c->amg = nullptr;
+}
+
+#define G256(n) dim3(((n) + 255) / 256 > 0 ? ((n) + 255) / 256 : 1), dim3(256), 0, c->stream
+
+// coarse matrices, block inverses and the Jacobi damping of every level, for the current K
+static int amg_numeric(feahip_ctx *c)
+{
+  AmgHierarchy *h = H(c);
+  const int nl = (int)h->lv.size();
+  for (int l = 0; l < nl; ++l) {
+    AmgLevel &L = h->lv[l];
+    hipLaunchKernelGGL(k_block_inverse, G256(L.N), L.N, L.diag, L.K, L.minv);
+    if (L.Nc > 0) {
+      AmgLevel &C = h->lv[l + 1];
+      hipLaunchKernelGGL(k_galerkin, G256(C.nnzb), C.nnzb, L.cbptr, L.cblist, L.K, C.K, L.cbrow, L.colidx,
+                         l == 0 ? c->d_dofmask : (const uint8_t *)nullptr);
+    }
+    // lambda_max(D^-1 K) by a few power iterations -> omega = 4 / (3 lambda_max)
+    double *v = (l == 0) ? h->d_pw : L.x, *y = (l == 0) ? c->d_q : L.y;
+    const int n = L.N * 3;
+    hipLaunchKernelGGL(k_fill_pattern, G256(n), n, v);
+    double lam = 1.0;
+    for (int it = 0; it < 8; ++it) {
+      enq_spmv_arrays(c->stream, L.nchunks, L.chunk, L.rowptr, L.colidx, L.K, v, y);
+      hipLaunchKernelGGL(k_apply_minv, G256(L.N), L.N, L.minv, y, v);
+      hipLaunchKernelGGL(k_norm2_serial, dim3(1), dim3(256), 0, c->stream, n, v, c->d_scal + 12);
+      double nrm2 = 0;
+      FEA_HIP_CHECK(c, hipMemcpyAsync(&nrm2, c->d_scal + 12, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+      if (!(nrm2 > 0) || nrm2 != nrm2) { lam = 2.0; break; }
+      lam = sqrt(nrm2);                       // v was normalised before the product
+      hipLaunchKernelGGL(k_scale, G256(n), n, 1.0 / lam, v);
+    }
+    L.omega = 4.0 / (3.0 * 1.1 * lam);        // 10 % margin: the power iteration approaches lambda_max from below
+  }
+  FEA_HIP_CHECK(c, hipGetLastError());
+  h->numeric_valid = true;
+  return FEAHIP_OK;
+}
+
+// x_l = cycle(r_l) from a zero initial guess: pre-smooth, `gamma` coarse
+// corrections (gamma = 1: V-cycle, 2: W-cycle), post-smooth.  Every step is a
+// fixed linear map and the cycle is symmetric in the K inner product
+// (I - M K = S' (I - P B P' K)^gamma S), which is what CG needs.  The coarse
+// correction of plain aggregation is too small by a mesh-independent factor;
+// `over` scales it (over-correction).
+static void amg_cycle(feahip_ctx *c, int l, const double *r, double *x, double *y)
+{
+  AmgHierarchy *h = H(c);
+  AmgLevel &L = h->lv[l];
+  const uint8_t *mask = l == 0 ? c->d_dofmask : (const uint8_t *)nullptr;
+  hipLaunchKernelGGL(k_smooth_first, G256(L.N), L.N, L.omega, L.minv, r, x);
+  if (L.Nc == 0) {
+    for (int s = 0; s < h->coarse_sweeps; ++s) {
+      enq_spmv_arrays(c->stream, L.nchunks, L.chunk, L.rowptr, L.colidx, L.K, x, y);
+      hipLaunchKernelGGL(k_smooth_next, G256(L.N), L.N, L.omega, L.minv, r, y, x);
+    }
+    return;
+  }
+  AmgLevel &C = h->lv[l + 1];
+  const int gamma = (l == 0) ? 1 : h->gamma;
+  for (int g = 0; g < gamma; ++g) {
+    enq_spmv_arrays(c->stream, L.nchunks, L.chunk, L.rowptr, L.colidx, L.K, x, y);
+    hipLaunchKernelGGL(k_restrict, G256(C.N * 3), C.N, L.aptr, L.anodes, r, y, mask, C.r);
+    amg_cycle(c, l + 1, C.r, C.x, C.y);
+    hipLaunchKernelGGL(k_prolong, G256(L.N * 3), L.N, L.agg, C.x, mask, h->over, x);
+  }
+  enq_spmv_arrays(c->stream, L.nchunks, L.chunk, L.rowptr, L.colidx, L.K, x, y);
+  hipLaunchKernelGGL(k_smooth_next, G256(L.N), L.N, L.omega, L.minv, r, y, x);
+}
+
+static void amg_vcycle(feahip_ctx *c, const double *r0, double *z0)
+{
+  amg_cycle(c, 0, r0, z0, c->d_q);
+}
+
+// PCG with the V-cycle as preconditioner (single rank).  Same recurrences,
+// device scalars and stop test as the block-Jacobi solver in kernels_solve.hip.
+int solve_pcg_amg(feahip_ctx *c, double tol, int max_iter, int *iters, double *resid)
+{
+  int rc;
+  if ((rc = amg_create(c))) return rc;
+  if ((rc = amg_numeric(c))) return rc;
+  AmgHierarchy *h = H(c);
+  FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_u, c->d_f, sizeof(double) * (size_t)c->ndof, hipMemcpyDeviceToDevice, c->stream));
+  enq_cg_init_plain(c);                         // r = f - K u0, partial r.r and b.b (p, r.z placeholders)
+  amg_vcycle(c, c->d_r, h->d_z);
+  enq_dot_rz(c, c->d_r, h->d_z);
+  enq_cg_init_scalars_plain(c, tol);
+  FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_p, h->d_z, sizeof(double) * (size_t)c->ndof, hipMemcpyDeviceToDevice, c->stream));
+  FEA_HIP_CHECK(c, hipGetLastError());
+  int flag = 0, it = 0;
+  const int batch = 8;
+  while (it < max_iter) {
+    const int n = (max_iter - it < batch) ? (max_iter - it) : batch;
+    for (int k = 0; k < n; ++k) {
+      enq_spmv_pq(c);                           // q = K p, partial p.q
+      enq_cg_update_plain(c, it + k);           // x += alpha p, r -= alpha q, partial r.r
+      amg_vcycle(c, c->d_r, h->d_z);            // z = V(r)   (uses q as scratch: q is dead after the update)
+      enq_dot_rz(c, c->d_r, h->d_z);            // partial r.z
+      enq_cg_direction_from(c, it + k, h->d_z); // beta, p = z + beta p, stop test
+    }
+    it += n;
+    FEA_HIP_CHECK(c, hipGetLastError());
+    FEA_HIP_CHECK(c, hipMemcpyAsync(&flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (flag != 0) break;
+  }
+  double sc[5];
+  FEA_HIP_CHECK(c, hipMemcpyAsync(sc, c->d_scal, sizeof(sc), hipMemcpyDeviceToHost, c->stream));
+  FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  int done_it = it;
+  if (flag == -1000000000) done_it = 0;
+  else if (flag > 0) done_it = flag;
+  else if (flag < 0) done_it = -flag;
+  if (iters) *iters = done_it;
+  if (resid) *resid = (sc[2] > 0) ? sqrt(sc[3] / sc[2]) : sqrt(sc[3]);
+  FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
+  if (flag < 0 && flag != -1000000000) {
+    c->err = "multigrid PCG breakdown at iteration " + std::to_string(-flag);
+    return FEAHIP_ENOTCONVERGED;
+  }
+  return FEAHIP_OK;
+}

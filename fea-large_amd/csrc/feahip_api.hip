@@ -1,5 +1,6 @@
 // feahip_api.hip -- extern "C" entry points of include/fea_hip.h.
 #include "feahip_internal.h"
+#include "amg.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -205,6 +206,7 @@ extern "C" void feahip_destroy(feahip_ctx *c)
   for (void *p : {(void *)c->d_send_idx, (void *)c->d_recv_idx, (void *)c->d_send_buf, (void *)c->d_recv_buf})
     if (p) (void)hipFree(p);
   if (c->tr && c->owns_tr) delete c->tr;
+  amg_destroy(c);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -225,6 +227,15 @@ extern "C" int feahip_set_assembly(feahip_ctx *c, int strategy)
   CTX_GUARD(c);
   if (strategy < FEAHIP_ASM_AUTO || strategy > FEAHIP_ASM_PAIRED) { c->err = "unknown assembly strategy"; return FEAHIP_EINVAL; }
   c->strategy = strategy;
+  return FEAHIP_OK;
+}
+
+extern "C" int feahip_set_preconditioner(feahip_ctx *c, int kind)
+{
+  CTX_GUARD(c);
+  if (kind != 0 && kind != 1) { c->err = "unknown preconditioner"; return FEAHIP_EINVAL; }
+  if (kind == 1) { int rc = amg_create(c); if (rc) return rc; }
+  c->precond = kind;
   return FEAHIP_OK;
 }
 
@@ -283,6 +294,10 @@ extern "C" int feahip_solve_slae(feahip_ctx *c, int type, double tol, int max_it
   CTX_GUARD(c);
   if (type < FEAHIP_CG || type > FEAHIP_CHOLESKY) { c->err = "unknown solver type"; return FEAHIP_EINVAL; }
   if (max_iter <= 0) { c->err = "max_iterations must be positive"; return FEAHIP_EINVAL; }
+  if (c->precond == 1 && type != FEAHIP_CG && c->nranks == 1) {
+    if (type == FEAHIP_CHOLESKY) { tol = 1e-16; if (max_iter < 100000) max_iter = 100000; }
+    return solve_pcg_amg(c, tol, max_iter, iters, resid);
+  }
   return solve_pcg(c, type, tol, max_iter, iters, resid);
 }
 

@@ -108,6 +108,10 @@ struct feahip_ctx {
   long long aux_bytes = 0;
 
   int last_bad = 0;
+
+  // preconditioner of PCG_ILU / CHOLESKY solves: 0 = 3x3 block-Jacobi, 1 = aggregation multigrid (amg.h)
+  int precond = 0;
+  void *amg = nullptr;         // AmgHierarchy, built on first use
 };
 
 #define FEA_HIP_CHECK(ctx, call)                                            \

@@ -314,7 +314,7 @@ void k_cg_init(int a0, int a1, const double *b, const double *q, const double *m
       r[(size_t)a * 3 + i] = rv[i];
     }
     for (int i = 0; i < 3; ++i) {
-      const double z = m[3 * i] * rv[0] + m[3 * i + 1] * rv[1] + m[3 * i + 2] * rv[2];
+      const double z = minv ? m[3 * i] * rv[0] + m[3 * i + 1] * rv[1] + m[3 * i + 2] * rv[2] : rv[i];
       p[(size_t)a * 3 + i] = z;
       srz += rv[i] * z; srr += rv[i] * rv[i]; sbb += bv[i] * bv[i];
     }
@@ -363,7 +363,7 @@ void k_cg_update(int a0, int a1, int it, int n_pq, const double *p, const double
       r[k] = rv[i];
     }
     for (int i = 0; i < 3; ++i) {
-      const double z = m[3 * i] * rv[0] + m[3 * i + 1] * rv[1] + m[3 * i + 2] * rv[2];
+      const double z = minv ? m[3 * i] * rv[0] + m[3 * i + 1] * rv[1] + m[3 * i + 2] * rv[2] : rv[i];
       srz += rv[i] * z; srr += rv[i] * rv[i];
     }
   }
@@ -391,7 +391,8 @@ void k_cg_direction(int a0, int a1, int it, int nparts, const double *r, const d
       const double r0 = r[(size_t)a * 3], r1 = r[(size_t)a * 3 + 1], r2 = r[(size_t)a * 3 + 2];
       for (int i = 0; i < 3; ++i) {
         const size_t k = (size_t)a * 3 + i;
-        p[k] = m[3 * i] * r0 + m[3 * i + 1] * r1 + m[3 * i + 2] * r2 + beta * p[k];
+        const double z = minv ? m[3 * i] * r0 + m[3 * i + 1] * r1 + m[3 * i + 2] * r2 : (i == 0 ? r0 : (i == 1 ? r1 : r2));
+        p[k] = z + beta * p[k];
       }
     }
   }
@@ -694,3 +695,44 @@ int time_pcg_iteration(feahip_ctx *c, int warmup, int iters, double *avg_ms)
   *avg_ms = iters > 0 ? (double)ms / iters : 0.0;
   return FEAHIP_OK;
 }
+
+// y = K x on any level of a hierarchy (amg.hip): same kernel, explicit arrays
+void enq_spmv_arrays(hipStream_t stream, int nchunks, const int *chunk, const int *rowptr, const int *colidx,
+                     const double *K, const double *xv, double *yv)
+{
+  int g = (nchunks + FEA_WAVES_PER_WG - 1) / FEA_WAVES_PER_WG;
+  g = g < FEA_RED_BLOCKS ? (g > 0 ? g : 1) : FEA_RED_BLOCKS;
+  hipLaunchKernelGGL(k_spmv, dim3(g), dim3(256), 0, stream, 0, nchunks, chunk, rowptr, colidx, K, xv, yv,
+                     (const double *)nullptr, (double *)nullptr, (const int *)nullptr);
+}
+
+// pieces of the PCG loop reused by the multigrid-preconditioned solve (amg.hip)
+void enq_cg_update_plain(feahip_ctx *c, int it)
+{
+  hipLaunchKernelGGL(k_cg_update, dim3(vgrid(c)), dim3(256), 0, c->stream, own0(c), own1(c), it, spmv_grid(c), c->d_p,
+                     c->d_q, (const double *)nullptr, c->d_u, c->d_r, c->d_part, (const double *)nullptr, c->d_scal, c->d_flag);
+}
+void enq_cg_direction_from(feahip_ctx *c, int it, const double *z)
+{
+  const int gv = vgrid(c);
+  hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(256), 0, c->stream, own0(c), own1(c), it, gv, z, (const double *)nullptr,
+                     c->d_p, c->d_part, (const double *)nullptr, c->d_scal, c->d_flag);
+}
+void enq_dot_rz(feahip_ctx *c, const double *r, const double *z)
+{
+  // same grid as the vector kernels: overwrites exactly the r.z partials k_cg_direction sums
+  hipLaunchKernelGGL(k_dot_partial, dim3(vgrid(c)), dim3(256), 0, c->stream, 3 * own0(c), 3 * own1(c), r, z, c->d_part + RB);
+}
+void enq_cg_init_plain(feahip_ctx *c)
+{
+  const int gv = vgrid(c);
+  enq_spmv_dot(c, c->d_u, c->d_q, nullptr, nullptr);
+  hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(256), 0, c->stream, own0(c), own1(c), c->d_f, c->d_q, (const double *)nullptr,
+                     c->d_r, c->d_p, c->d_part);
+}
+void enq_cg_init_scalars_plain(feahip_ctx *c, double tol)
+{
+  hipLaunchKernelGGL(k_cg_init_scalars, dim3(1), dim3(256), 0, c->stream, vgrid(c), c->d_part, (const double *)nullptr,
+                     c->d_scal, tol, c->d_flag);
+}
+void enq_spmv_pq(feahip_ctx *c) { enq_spmv_dot(c, c->d_p, c->d_q, c->d_p, c->d_part); }

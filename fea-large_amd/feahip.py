@@ -54,6 +54,7 @@ ABI = {
     "feahip_get_matrix_yale": [C.c_void_p, _ip, _ip, _dp],
     "feahip_spmv": [C.c_void_p, _dp, _dp],
     "feahip_set_assembly": [C.c_void_p, C.c_int],
+    "feahip_set_preconditioner": [C.c_void_p, C.c_int],
     "feahip_set_row_shard": [C.c_void_p, C.c_int, C.c_int],
     "feahip_comm_unique_id": [C.c_void_p, C.c_int],
     "feahip_comm_init": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
@@ -405,6 +406,9 @@ class FeaSolver:
         return y
 
     # ---- tuning / measurement ------------------------------------------
+    def set_preconditioner(self, kind):
+        self._chk(self._lib.feahip_set_preconditioner(self._ctx, kind))
+
     def set_assembly(self, strategy):
         self._chk(self._lib.feahip_set_assembly(self._ctx, strategy))
 

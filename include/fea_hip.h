@@ -199,6 +199,11 @@ int feahip_spmv(feahip_ctx *ctx, const double *x, double *y);
 /* ---- tuning and measurement -------------------------------------------- */
 
 int feahip_set_assembly(feahip_ctx *ctx, int strategy);
+/* Preconditioner of the PCG_ILU / CHOLESKY solves: 0 = inverse 3x3 diagonal
+ * blocks (default), 1 = aggregation multigrid V-cycle (single rank; a sharded
+ * context keeps block-Jacobi).  Either way the solve runs to the requested
+ * residual, so the solution is the same to that tolerance.                   */
+int feahip_set_preconditioner(feahip_ctx *ctx, int kind);
 /* Restricts assembly and SpMV to this rank's slab of block rows (rank of
  * nranks, contiguous row ranges of near-equal block count).  Rows are owned
  * by exactly one rank; a rank visits every element that touches its rows, so
