@@ -225,7 +225,7 @@ extern "C" int feahip_sync(feahip_ctx *c)
 extern "C" int feahip_set_assembly(feahip_ctx *c, int strategy)
 {
   CTX_GUARD(c);
-  if (strategy < FEAHIP_ASM_AUTO || strategy > FEAHIP_ASM_PAIRED) { c->err = "unknown assembly strategy"; return FEAHIP_EINVAL; }
+  if (strategy < FEAHIP_ASM_AUTO || strategy > FEAHIP_ASM_PIPELINED) { c->err = "unknown assembly strategy"; return FEAHIP_EINVAL; }
   c->strategy = strategy;
   return FEAHIP_OK;
 }

@@ -190,7 +190,7 @@ struct HostPairs {
 };
 void build_host_pairs(const int *conn, const HostPattern &hp, const HostVisits &hv, HostPairs &out);
 int launch_assemble_pair(feahip_ctx *c, bool doK, bool doF);
-int launch_assemble_visit(feahip_ctx *c, bool doK, bool doF);
+int launch_assemble_visit(feahip_ctx *c, bool doK, bool doF, bool pipelined);
 
 // launchers (kernels_assemble.hip / kernels_patch.hip / kernels_solve.hip)
 int launch_assemble_patch(feahip_ctx *c, bool doF);

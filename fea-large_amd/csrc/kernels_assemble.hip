@@ -306,13 +306,13 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
     if (doK) FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));
     return launch_assemble_pair(c, doK, doF);
   }
-  if (strat == FEAHIP_ASM_STAGED) {
+  if (strat == FEAHIP_ASM_STAGED || strat == FEAHIP_ASM_PIPELINED) {
     if (!c->have_visits) {
       c->err = "staged assembly needs linear tetrahedra whose chunks fit the LDS tiles";
       return FEAHIP_EINVAL;
     }
     if (doK) FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));
-    return launch_assemble_visit(c, doK, doF);
+    return launch_assemble_visit(c, doK, doF, strat == FEAHIP_ASM_PIPELINED);
   }
   if (strat == FEAHIP_ASM_PATCH && !doK) strat = FEAHIP_ASM_ROWOWNER;   // residual alone: visit kernel
   if (strat == FEAHIP_ASM_PATCH) {

@@ -148,6 +148,8 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
   std::vector<char> bad((size_t)np, 0);
   const char *ord = getenv("FEAHIP_VISIT_ORDER");
   const bool interleave_rows = !(ord && ord[0] == '1');
+  const bool bank_aware = !(ord && (ord[0] == '0' || ord[0] == '1'));
+  const int nsweeps = (ord && ord[0] == '3') ? 2 : 0;
   par_for(np, [&](int lo, int hi) {
     std::vector<int> halo;
     for (int p = lo; p < hi; ++p) {
@@ -179,15 +181,6 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
         if (g >= r0 && g < r1) return g - r0;
         return nown + (int)(std::lower_bound(halo.begin(), halo.end(), g) - halo.begin());
       };
-      // Schedule of the chunk's visits.  A pass of the kernel = 64 visits, each
-      // adding its three off-diagonal blocks in three steps; lanes that add to
-      // the same (row, column) block in the same step serialise in the LDS
-      // (~11 clk per extra lane).  So (1) the visits of every row are split
-      // over the passes keeping each column's count per pass low, and (2) each
-      // visit's three column nodes are ordered so that, step by step, the
-      // visits of one row in one pass hit different columns (greedy
-      // edge-colouring of the visit x column graph).
-      const int nrounds = (d.nvisit + 63) / 64;
       struct V { uint32_t w; int row; int slot[3]; int node[3]; int round; int order[3]; };
       std::vector<V> vs;
       vs.reserve((size_t)d.nvisit);
@@ -206,56 +199,165 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
           v.order[0] = 0; v.order[1] = 1; v.order[2] = 2;
           vs.push_back(v);
         }
-      // (1) pass of every visit
-      std::vector<int> rsize((size_t)nrounds, 0);
-      std::vector<uint8_t> deg((size_t)nrounds * nown * 256, 0);
-      auto D = [&](int rd, int row, int slot) -> uint8_t & { return deg[((size_t)rd * nown + row) * 256 + slot]; };
-      const int cap = (d.nvisit + nrounds - 1) / nrounds;
-      for (auto &v : vs) {
-        int best = -1, bestcost = 1 << 30;
-        for (int rd = 0; rd < nrounds; ++rd) {
-          if (rsize[rd] >= std::min(64, cap)) continue;
-          int mx = 0;
-          for (int m = 0; m < 3; ++m) mx = std::max(mx, (int)D(rd, v.row, v.slot[m]));
-          const int cost = mx * 1024 + rsize[rd];
-          if (cost < bestcost) { bestcost = cost; best = rd; }
-        }
-        if (best < 0) best = (int)(std::min_element(rsize.begin(), rsize.end()) - rsize.begin());
-        v.round = best; rsize[best]++;
-        for (int m = 0; m < 3; ++m) D(best, v.row, v.slot[m])++;
-      }
-      // (2) step of every column inside its visit
       static const int perms[6][3] = {{0, 1, 2}, {1, 2, 0}, {2, 0, 1}, {0, 2, 1}, {2, 1, 0}, {1, 0, 2}};
-      std::vector<uint8_t> used((size_t)nrounds * nown * 3 * 256, 0);
-      auto U = [&](int rd, int row, int step, int slot) -> uint8_t & { return used[(((size_t)rd * nown + row) * 3 + step) * 256 + slot]; };
-      for (auto &v : vs) {
-        int bestp = 0, bestc = 1 << 30;
-        for (int pi = 0; pi < 6; ++pi) {
+      if (bank_aware) {
+        // Schedule of the chunk's visits against LDS bank conflicts.  A pass
+        // of the kernel = 64 visits, each adding its three off-diagonal blocks
+        // in three steps of nine ds_add_f64.  The LDS serves a 64-lane f64
+        // atomic as four groups of 16 consecutive lanes, and inside a group
+        // two lanes collide when their addresses agree mod 16 doubles
+        // (profiles/r01_microbench_lds_f64_atomic.txt: 8.3 clk conflict-free,
+        // 26 clk for random blocks).  A block at tile position p sits at
+        // doubles 9p..9p+8, and 9 is odd: lanes collide iff their blocks agree
+        // mod 16.  So the visits are dealt to groups of 16 lanes, and each
+        // visit's three columns to the three steps, so that inside a group the
+        // blocks of one step are distinct mod 16: greedy, least collisions
+        // first, then a pass of pairwise swaps for the visits still colliding.
+        const int n = (int)vs.size();
+        const int ngroups = (n + 15) / 16;
+        // pos = tile position of the block; two lanes on one block (same address) serialise
+        // harder than two blocks on one bank, so that costs 4 collisions
+        std::vector<int> pos((size_t)n * 3);
+        for (int i = 0; i < n; ++i)
+          for (int m = 0; m < 3; ++m) pos[(size_t)i * 3 + m] = hp.rowptr[r0 + vs[i].row] - b0 + vs[i].slot[m];
+        std::vector<uint8_t> cnt((size_t)ngroups * 3 * 16, 0), cnta((size_t)ngroups * 3 * 256, 0);
+        auto CA = [&](int g, int st, int ps) -> uint8_t & { return cnta[((size_t)g * 3 + st) * 256 + ps]; };
+        std::vector<int> gsize((size_t)ngroups, 0), gof((size_t)n, -1), pof((size_t)n, 0);
+        auto C = [&](int g, int st, int res) -> uint8_t & { return cnt[((size_t)g * 3 + st) * 16 + res]; };
+        auto cap = [&](int g) { return std::min(16, n - 16 * g); };
+        auto cost_in = [&](int i, int g, int pi) {
           int cst = 0;
-          for (int st = 0; st < 3; ++st) cst += U(v.round, v.row, st, v.slot[perms[pi][st]]);
-          if (cst < bestc) { bestc = cst; bestp = pi; }
-        }
-        for (int st = 0; st < 3; ++st) { v.order[st] = perms[bestp][st]; U(v.round, v.row, st, v.slot[v.order[st]])++; }
-      }
-      // emit pass by pass
-      std::stable_sort(vs.begin(), vs.end(), [](const V &x, const V &y) { return x.round < y.round; });
-      if (interleave_rows) {
-        // inside a pass, deal the visits round-robin over the rows
-        std::vector<V> tmp2; tmp2.reserve(vs.size());
-        size_t b = 0;
-        while (b < vs.size()) {
-          size_t e2 = b;
-          while (e2 < vs.size() && vs[e2].round == vs[b].round) ++e2;
-          std::vector<std::vector<V>> per((size_t)nown);
-          for (size_t i = b; i < e2; ++i) per[(size_t)vs[i].row].push_back(vs[i]);
+          for (int st = 0; st < 3; ++st) {
+            const int ps = pos[(size_t)i * 3 + perms[pi][st]];
+            cst += C(g, st, ps & 15) + 3 * CA(g, st, ps);
+          }
+          return cst;
+        };
+        auto put = [&](int i, int g, int pi, int delta) {
+          for (int st = 0; st < 3; ++st) {
+            const int ps = pos[(size_t)i * 3 + perms[pi][st]];
+            C(g, st, ps & 15) = (uint8_t)(C(g, st, ps & 15) + delta);
+            CA(g, st, ps) = (uint8_t)(CA(g, st, ps) + delta);
+          }
+          gsize[g] += delta;
+        };
+        // deal order: round-robin over the rows, so a group mixes rows evenly
+        std::vector<int> order; order.reserve((size_t)n);
+        {
+          std::vector<std::vector<int>> per((size_t)nown);
+          for (int i = 0; i < n; ++i) per[(size_t)vs[i].row].push_back(i);
           for (size_t k = 0;; ++k) {
             bool any = false;
-            for (auto &pr : per) if (k < pr.size()) { tmp2.push_back(pr[k]); any = true; }
+            for (auto &pr : per) if (k < pr.size()) { order.push_back(pr[k]); any = true; }
             if (!any) break;
           }
-          b = e2;
         }
-        vs.swap(tmp2);
+        for (int i : order) {
+          int bg = -1, bp = 0, bc = 1 << 30;
+          for (int g = 0; g < ngroups; ++g) {
+            if (gsize[g] >= cap(g)) continue;
+            for (int pi = 0; pi < 6; ++pi) {
+              const int cst = cost_in(i, g, pi) * 64 + gsize[g];
+              if (cst < bc) { bc = cst; bg = g; bp = pi; }
+            }
+          }
+          gof[i] = bg; pof[i] = bp; put(i, bg, bp, +1);
+        }
+        // pairwise swaps for the visits that still collide
+        for (int sweep = 0; sweep < nsweeps; ++sweep) {
+          bool changed = false;
+          for (int i = 0; i < n; ++i) {
+            put(i, gof[i], pof[i], -1);
+            const int ci = cost_in(i, gof[i], pof[i]);
+            put(i, gof[i], pof[i], +1);
+            if (ci == 0) continue;
+            int best_j = -1, best_pi = 0, best_pj = 0, best_gain = 0;
+            for (int j = 0; j < n; ++j) {
+              if (gof[j] == gof[i]) continue;
+              const int gi = gof[i], gj = gof[j];
+              put(i, gi, pof[i], -1); put(j, gj, pof[j], -1);
+              const int before = cost_in(i, gi, pof[i]) + cost_in(j, gj, pof[j]);
+              int ai = 1 << 30, api = 0, aj = 1 << 30, apj = 0;
+              for (int pi = 0; pi < 6; ++pi) {
+                const int x = cost_in(i, gj, pi); if (x < ai) { ai = x; api = pi; }
+                const int y = cost_in(j, gi, pi); if (y < aj) { aj = y; apj = pi; }
+              }
+              put(i, gi, pof[i], +1); put(j, gj, pof[j], +1);
+              const int gain = before - (ai + aj);
+              if (gain > best_gain) { best_gain = gain; best_j = j; best_pi = api; best_pj = apj; }
+            }
+            if (best_j >= 0) {
+              const int j = best_j, gi = gof[i], gj = gof[j];
+              put(i, gi, pof[i], -1); put(j, gj, pof[j], -1);
+              gof[i] = gj; pof[i] = best_pi; gof[j] = gi; pof[j] = best_pj;
+              put(i, gj, best_pi, +1); put(j, gi, best_pj, +1);
+              changed = true;
+            }
+          }
+          if (!changed) break;
+        }
+        for (int i = 0; i < n; ++i) { vs[i].round = gof[i]; for (int st = 0; st < 3; ++st) vs[i].order[st] = perms[pof[i]][st]; }
+        std::stable_sort(vs.begin(), vs.end(), [](const V &x, const V &y) { return x.round < y.round; });
+      } else {
+        // Legacy schedule (FEAHIP_VISIT_ORDER=0/1).  A pass of the kernel = 64 visits, each
+        // adding its three off-diagonal blocks in three steps; lanes that add to
+        // the same (row, column) block in the same step serialise in the LDS
+        // (~11 clk per extra lane).  So (1) the visits of every row are split
+        // over the passes keeping each column's count per pass low, and (2) each
+        // visit's three column nodes are ordered so that, step by step, the
+        // visits of one row in one pass hit different columns (greedy
+        // edge-colouring of the visit x column graph).
+        const int nrounds = (d.nvisit + 63) / 64;
+        // (1) pass of every visit
+        std::vector<int> rsize((size_t)nrounds, 0);
+        std::vector<uint8_t> deg((size_t)nrounds * nown * 256, 0);
+        auto D = [&](int rd, int row, int slot) -> uint8_t & { return deg[((size_t)rd * nown + row) * 256 + slot]; };
+        const int cap = (d.nvisit + nrounds - 1) / nrounds;
+        for (auto &v : vs) {
+          int best = -1, bestcost = 1 << 30;
+          for (int rd = 0; rd < nrounds; ++rd) {
+            if (rsize[rd] >= std::min(64, cap)) continue;
+            int mx = 0;
+            for (int m = 0; m < 3; ++m) mx = std::max(mx, (int)D(rd, v.row, v.slot[m]));
+            const int cost = mx * 1024 + rsize[rd];
+            if (cost < bestcost) { bestcost = cost; best = rd; }
+          }
+          if (best < 0) best = (int)(std::min_element(rsize.begin(), rsize.end()) - rsize.begin());
+          v.round = best; rsize[best]++;
+          for (int m = 0; m < 3; ++m) D(best, v.row, v.slot[m])++;
+        }
+        // (2) step of every column inside its visit
+        std::vector<uint8_t> used((size_t)nrounds * nown * 3 * 256, 0);
+        auto U = [&](int rd, int row, int step, int slot) -> uint8_t & { return used[(((size_t)rd * nown + row) * 3 + step) * 256 + slot]; };
+        for (auto &v : vs) {
+          int bestp = 0, bestc = 1 << 30;
+          for (int pi = 0; pi < 6; ++pi) {
+            int cst = 0;
+            for (int st = 0; st < 3; ++st) cst += U(v.round, v.row, st, v.slot[perms[pi][st]]);
+            if (cst < bestc) { bestc = cst; bestp = pi; }
+          }
+          for (int st = 0; st < 3; ++st) { v.order[st] = perms[bestp][st]; U(v.round, v.row, st, v.slot[v.order[st]])++; }
+        }
+        // emit pass by pass
+        std::stable_sort(vs.begin(), vs.end(), [](const V &x, const V &y) { return x.round < y.round; });
+        if (interleave_rows) {
+          // inside a pass, deal the visits round-robin over the rows
+          std::vector<V> tmp2; tmp2.reserve(vs.size());
+          size_t b = 0;
+          while (b < vs.size()) {
+            size_t e2 = b;
+            while (e2 < vs.size() && vs[e2].round == vs[b].round) ++e2;
+            std::vector<std::vector<V>> per((size_t)nown);
+            for (size_t i = b; i < e2; ++i) per[(size_t)vs[i].row].push_back(vs[i]);
+            for (size_t k = 0;; ++k) {
+              bool any = false;
+              for (auto &pr : per) if (k < pr.size()) { tmp2.push_back(pr[k]); any = true; }
+              if (!any) break;
+            }
+            b = e2;
+          }
+          vs.swap(tmp2);
+        }
       }
       for (int i = 0; i < (int)vs.size(); ++i) {
         const V &v = vs[i];

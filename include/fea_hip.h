@@ -51,10 +51,15 @@ enum {
                               reproducible                                   */
   FEAHIP_ASM_STAGED = 4,   /* linear tets: row-owner visits with node
                               coordinates and connectivity staged in LDS     */
-  FEAHIP_ASM_PAIRED = 5    /* STAGED with two face-sharing elements per lane:
+  FEAHIP_ASM_PAIRED = 5,   /* STAGED with two face-sharing elements per lane:
                               shared blocks summed in registers (fewer LDS
                               operations; measured 5 % slower than STAGED
                               for K+f, 8 % faster for f alone)               */
+  FEAHIP_ASM_PIPELINED = 6 /* STAGED, one wave walking a run of chunks with
+                              the next chunk's loads (LDS-DMA) in flight
+                              under the current one; hides the load latency
+                              but the LDS adds bound both: equal to STAGED
+                              within 2 %                         */
 };
 
 /* ---- lifetime ----------------------------------------------------------- */

@@ -37,7 +37,7 @@ def make_pair(deck, x=None):
 
 def check_assembly(s, o, strategies=(feahip.ASM_ROWOWNER, feahip.ASM_ATOMIC)):
     if s.npe == 4 and s.G == 1:
-        strategies = tuple(strategies) + (feahip.ASM_PATCH, feahip.ASM_STAGED, feahip.ASM_PAIRED)
+        strategies = tuple(strategies) + (feahip.ASM_PATCH, feahip.ASM_STAGED, feahip.ASM_PAIRED, feahip.ASM_PIPELINED)
     o.update_state()
     o.create_stiffness()
     o.create_residual_forces()
