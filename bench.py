@@ -205,19 +205,37 @@ def main():
             extras["pcg_iteration_ms"] = solver.time_kernel(4, warmup=2, iters=10)      # collective when sharded
             if not args.no_newton:
                 # one full Newton iteration of the first load increment: bump, assemble, BC, PCG to 1e-14, update
-                solver.set_nodes(deck.nodes)
-                solver.sync(); barrier()
-                tn = time.perf_counter()
-                solver.update_nodes_with_bc(1.0)
-                solver.create_stiffness_and_residual()
-                solver.apply_prescribed_bc(0.0)
-                its, res = solver.solve_slae(feahip.PCG_ILU, 1e-14, 20000)
-                en = solver.energy()
-                solver.update_nodes_with_solution()
-                solver.sync(); barrier()
-                tn = time.perf_counter() - tn
+                def newton_iteration():
+                    solver.set_nodes(deck.nodes)
+                    solver.sync(); barrier()
+                    t0 = time.perf_counter()
+                    solver.update_nodes_with_bc(1.0)
+                    solver.create_stiffness_and_residual()
+                    solver.apply_prescribed_bc(0.0)
+                    its, res = solver.solve_slae(feahip.PCG_ILU, 1e-14, 20000)
+                    en = solver.energy()
+                    solver.update_nodes_with_solution()
+                    solver.sync(); barrier()
+                    return time.perf_counter() - t0, its, res, en
+
+                tn, its, res, en = newton_iteration()
                 extras.update({"newton_iters_per_s": 1.0 / tn, "newton_iteration_s": tn, "cg_iterations": its,
-                               "cg_relative_residual": res, "energy_u_f": en})
+                               "cg_relative_residual": res, "energy_u_f": en,
+                               "newton_preconditioner": "3x3 block-Jacobi"})
+                if world == 1:
+                    # same iteration with the aggregation-multigrid preconditioner (single rank only);
+                    extras["block_jacobi"] = {"newton_iteration_s": tn, "cg_iterations": its}
+                    t_amg = time.perf_counter()
+                    solver.set_preconditioner(1)          # builds the aggregates and coarse patterns on the host, once
+                    t_amg = time.perf_counter() - t_amg
+                    newton_iteration()
+                    tn, its, res, en2 = newton_iteration()
+                    extras.update({"newton_iters_per_s": 1.0 / tn, "newton_iteration_s": tn, "cg_iterations": its,
+                                   "cg_relative_residual": res, "energy_u_f": en2,
+                                   "newton_preconditioner": "aggregation multigrid (rigid-body modes), W-cycle",
+                                   "amg_setup_s": t_amg,
+                                   "energy_u_f_block_jacobi": en})
+                    solver.set_preconditioner(0)
         except Exception as e:                      # noqa: BLE001
             extras["solve_leg"] = f"failed: {e}"
         watchdog.cancel()

@@ -17,29 +17,52 @@ void enq_spmv_pq(feahip_ctx *c);
 // kernels
 // ---------------------------------------------------------------------------
 
-// coarse block = sum of its fine blocks, in list order (deterministic).  On
-// level 0 the prescribed dofs are left out of the coarse space (their rows of
-// the prolongator are zero): entries in a masked row or column are skipped.
-__global__ void k_galerkin(int nnzc, const int *cbptr, const int *cblist, const double *Kf, double *Kc,
-                           const int *cbrow, const int *colidx_f, const uint8_t *mask)
+// Coarse block (I kind s, J kind r) = sum over the fine blocks (i, j) of the
+// aggregate pair, in list order (deterministic), of  P_is' K_ij P_jr, where a
+// translation row i has P_i0 = I, P_i1 = R(d_i) (u = t + w x d, R(d) w = w x d)
+// and a rotation row has P_i0 = 0, P_i1 = I.  R(d)' B crosses every column of
+// B with d from the left, B R(d) every row.  On level 0 the prescribed dofs are
+// left out of the coarse space: their rows and columns of K_ij are skipped.
+__device__ __forceinline__ void cross3(const double *d, double a0, double a1, double a2, double &o0, double &o1, double &o2)
+{
+  o0 = d[1] * a2 - d[2] * a1; o1 = d[2] * a0 - d[0] * a2; o2 = d[0] * a1 - d[1] * a0;
+}
+__global__ void k_galerkin(int nnzc, const int *kpair, const uint8_t *ksr, const int *cbptr, const int *cblist,
+                           const double *Kf, double *Kc, const int *cbrow, const int *colidx_f, const uint8_t *type_f,
+                           const double *doff, const uint8_t *mask)
 {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nnzc) return;
+  const int kp = kpair[k], sg = ksr[k] >> 1, rho = ksr[k] & 1;
   double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int p = cbptr[k]; p < cbptr[k + 1]; ++p) {
+  for (int p = cbptr[kp]; p < cbptr[kp + 1]; ++p) {
     const int q = cblist[p];
-    const double *b = Kf + (size_t)q * 9;
+    const int i = cbrow[q], j = colidx_f[q];
+    const int ti = type_f ? type_f[i] : 0, tj = type_f ? type_f[j] : 0;
+    if ((ti == 1 && sg == 0) || (tj == 1 && rho == 0)) continue;
+    double m[9];
+    const double *bq = Kf + (size_t)q * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) m[t] = bq[t];
     if (mask) {
-      const int i = cbrow[q], j = colidx_f[q];
 #pragma unroll
       for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int bb = 0; bb < 3; ++bb)
-          if (!mask[3 * i + a] && !mask[3 * j + bb]) acc[3 * a + bb] += b[3 * a + bb];
-    } else {
-#pragma unroll
-      for (int t = 0; t < 9; ++t) acc[t] += b[t];
+          if (mask[3 * i + a] || mask[3 * j + bb]) m[3 * a + bb] = 0.0;
     }
+    if (ti == 0 && sg == 1) {
+      const double *d = doff + (size_t)i * 3;
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) cross3(d, m[cc], m[3 + cc], m[6 + cc], m[cc], m[3 + cc], m[6 + cc]);
+    }
+    if (tj == 0 && rho == 1) {
+      const double *d = doff + (size_t)j * 3;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) cross3(d, m[3 * r], m[3 * r + 1], m[3 * r + 2], m[3 * r], m[3 * r + 1], m[3 * r + 2]);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] += m[t];
   }
   double *o = Kc + (size_t)k * 9;
 #pragma unroll
@@ -89,28 +112,52 @@ __global__ void k_smooth_next(int N, double omega, const double *minv, const dou
   for (int i = 0; i < 3; ++i) x[(size_t)a * 3 + i] += omega * (m[3 * i] * t0 + m[3 * i + 1] * t1 + m[3 * i + 2] * t2);
 }
 
-// r_c[I] = sum_{i in I} (r[i] - y[i])     (P' (r - K x)), nodes in list order
-__global__ void k_restrict(int Nc, const int *aptr, const int *anodes, const double *r, const double *y,
-                           const uint8_t *mask, double *rc)
+// r_c = P' (r - K x): translation row of aggregate A = sum of the residuals of
+// its translation rows, rotation row = sum of their moments d x res plus the
+// residuals of its rotation rows; members in list order
+__global__ void k_restrict(int nagg, const int *aptr, const int *anodes, const uint8_t *type_f, const double *doff,
+                           const double *r, const double *y, const uint8_t *mask, double *rc)
 {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= Nc * 3) return;
-  const int I = t / 3, d = t % 3;
-  double acc = 0;
-  for (int p = aptr[I]; p < aptr[I + 1]; ++p) {
-    const size_t k = (size_t)anodes[p] * 3 + d;
-    if (!mask || !mask[k]) acc += r[k] - y[k];
+  const int A = blockIdx.x * blockDim.x + threadIdx.x;
+  if (A >= nagg) return;
+  double t0 = 0, t1 = 0, t2 = 0, w0 = 0, w1 = 0, w2 = 0;
+  for (int p = aptr[A]; p < aptr[A + 1]; ++p) {
+    const int i = anodes[p];
+    const size_t k = (size_t)i * 3;
+    double a0 = r[k] - y[k], a1 = r[k + 1] - y[k + 1], a2 = r[k + 2] - y[k + 2];
+    if (mask) { if (mask[k]) a0 = 0; if (mask[k + 1]) a1 = 0; if (mask[k + 2]) a2 = 0; }
+    if (type_f && type_f[i]) { w0 += a0; w1 += a1; w2 += a2; }
+    else {
+      t0 += a0; t1 += a1; t2 += a2;
+      double m0, m1, m2;
+      cross3(doff + k, a0, a1, a2, m0, m1, m2);
+      w0 += m0; w1 += m1; w2 += m2;
+    }
   }
-  rc[t] = acc;
+  double *o = rc + (size_t)A * 6;
+  o[0] = t0; o[1] = t1; o[2] = t2; o[3] = w0; o[4] = w1; o[5] = w2;
 }
 
-// x[i] += x_c[agg(i)]                      (P x_c)
-__global__ void k_prolong(int N, const int *agg, const double *xc, const uint8_t *mask, double over, double *x)
+// x += over * P x_c : translation row i gets t + w x d_i, rotation row gets w
+__global__ void k_prolong(int N, const int *agg, const uint8_t *type_f, const double *doff, const double *xc,
+                          const uint8_t *mask, double over, double *x)
 {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= N * 3) return;
-  if (mask && mask[t]) return;
-  x[t] += over * xc[(size_t)agg[t / 3] * 3 + t % 3];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double *c6 = xc + (size_t)agg[i] * 6;
+  const size_t k = (size_t)i * 3;
+  double u0, u1, u2;
+  if (type_f && type_f[i]) { u0 = c6[3]; u1 = c6[4]; u2 = c6[5]; }
+  else {
+    const double dd[3] = {doff[k], doff[k + 1], doff[k + 2]};
+    // w x d
+    u0 = c6[0] + (c6[4] * dd[2] - c6[5] * dd[1]);
+    u1 = c6[1] + (c6[5] * dd[0] - c6[3] * dd[2]);
+    u2 = c6[2] + (c6[3] * dd[1] - c6[4] * dd[0]);
+  }
+  if (!mask || !mask[k]) x[k] += over * u0;
+  if (!mask || !mask[k + 1]) x[k + 1] += over * u1;
+  if (!mask || !mask[k + 2]) x[k + 2] += over * u2;
 }
 
 // power iteration helpers for lambda_max(D^-1 K)
@@ -169,7 +216,13 @@ int amg_create(feahip_ctx *c)
 {
   if (c->amg) return FEAHIP_OK;
   std::vector<HostAmgLevel> hl;
-  if (!build_host_amg(c->h_rowptr, c->h_colidx, hl)) {
+  std::vector<double> pos((size_t)c->N * 3);
+  {                                   // aggregate geometry from the reference configuration
+    std::vector<double> pad((size_t)c->N * 4);
+    FEA_HIP_CHECK(c, hipMemcpy(pad.data(), c->d_X0, sizeof(double) * pad.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < c->N; ++i) for (int d = 0; d < 3; ++d) pos[(size_t)i * 3 + d] = pad[(size_t)i * 4 + d];
+  }
+  if (!build_host_amg(c->h_rowptr, c->h_colidx, pos, hl)) {
     c->err = "multigrid hierarchy unavailable for this mesh (too small, or a coarse row exceeds the SpMV chunk)";
     return FEAHIP_EINVAL;
   }
@@ -183,7 +236,7 @@ int amg_create(feahip_ctx *c)
   for (size_t l = 0; l < hl.size(); ++l) {
     AmgLevel &L = h->lv[l];
     const HostAmgLevel &S = hl[l];
-    L.N = S.N; L.nnzb = (int)S.colidx.size(); L.nchunks = (int)S.chunk.size() - 1; L.Nc = S.Nc;
+    L.N = S.N; L.nnzb = (int)S.colidx.size(); L.nchunks = (int)S.chunk.size() - 1; L.Nc = 2 * S.Sc;
     if (l == 0) {
       L.rowptr = c->d_rowptr; L.colidx = c->d_colidx; L.diag = c->d_diag; L.chunk = c->d_chunk; L.K = c->d_K;
       L.nchunks = c->nchunks;
@@ -197,15 +250,19 @@ int amg_create(feahip_ctx *c)
       if ((rc = zeros(c, &L.r, (size_t)L.N * 3, h->bytes))) return rc;
       if ((rc = zeros(c, &L.x, (size_t)L.N * 3, h->bytes))) return rc;
       if ((rc = zeros(c, &L.y, (size_t)L.N * 3, h->bytes))) return rc;
+      if ((rc = up(c, &L.type, S.type, h->bytes))) return rc;
     }
     if ((rc = zeros(c, &L.minv, (size_t)L.N * 9, h->bytes))) return rc;
-    if (S.Nc > 0) {
+    if (S.Sc > 0) {
       if ((rc = up(c, &L.agg, S.agg, h->bytes))) return rc;
+      if ((rc = up(c, &L.doff, S.doff, h->bytes))) return rc;
       if ((rc = up(c, &L.aptr, S.aptr, h->bytes))) return rc;
       if ((rc = up(c, &L.anodes, S.anodes, h->bytes))) return rc;
       if ((rc = up(c, &L.cbptr, S.cbptr, h->bytes))) return rc;
       if ((rc = up(c, &L.cblist, S.cblist, h->bytes))) return rc;
-      if (l == 0 && (rc = up(c, &L.cbrow, S.cbrow, h->bytes))) return rc;
+      if ((rc = up(c, &L.kpair, S.kpair, h->bytes))) return rc;
+      if ((rc = up(c, &L.ksr, S.ksr, h->bytes))) return rc;
+      if ((rc = up(c, &L.cbrow, S.cbrow, h->bytes))) return rc;
     }
   }
   if ((rc = zeros(c, &h->d_z, (size_t)c->ndof, h->bytes))) return rc;
@@ -218,7 +275,7 @@ void amg_destroy(feahip_ctx *c)
   AmgHierarchy *h = H(c);
   if (!h) return;
   for (AmgLevel &L : h->lv) {
-    void *own[] = {L.minv, L.agg, L.aptr, L.anodes, L.cbptr, L.cblist, L.cbrow, L.r, L.x, L.y};
+    void *own[] = {L.minv, L.agg, L.doff, L.aptr, L.anodes, L.cbptr, L.cblist, L.kpair, L.ksr, L.cbrow, L.r, L.x, L.y, L.type};
     for (void *p : own) if (p) (void)hipFree(p);
     if (L.owns_matrix) { void *m[] = {L.rowptr, L.colidx, L.diag, L.chunk, L.K}; for (void *p : m) if (p) (void)hipFree(p); }
   }
@@ -240,8 +297,8 @@ static int amg_numeric(feahip_ctx *c)
     hipLaunchKernelGGL(k_block_inverse, G256(L.N), L.N, L.diag, L.K, L.minv);
     if (L.Nc > 0) {
       AmgLevel &C = h->lv[l + 1];
-      hipLaunchKernelGGL(k_galerkin, G256(C.nnzb), C.nnzb, L.cbptr, L.cblist, L.K, C.K, L.cbrow, L.colidx,
-                         l == 0 ? c->d_dofmask : (const uint8_t *)nullptr);
+      hipLaunchKernelGGL(k_galerkin, G256(C.nnzb), C.nnzb, L.kpair, L.ksr, L.cbptr, L.cblist, L.K, C.K, L.cbrow, L.colidx,
+                         L.type, L.doff, l == 0 ? c->d_dofmask : (const uint8_t *)nullptr);
     }
     // lambda_max(D^-1 K) by a few power iterations -> omega = 4 / (3 lambda_max)
     double *v = (l == 0) ? h->d_pw : L.x, *y = (l == 0) ? c->d_q : L.y;
@@ -289,9 +346,9 @@ static void amg_cycle(feahip_ctx *c, int l, const double *r, double *x, double *
   const int gamma = (l == 0) ? 1 : h->gamma;
   for (int g = 0; g < gamma; ++g) {
     enq_spmv_arrays(c->stream, L.nchunks, L.chunk, L.rowptr, L.colidx, L.K, x, y);
-    hipLaunchKernelGGL(k_restrict, G256(C.N * 3), C.N, L.aptr, L.anodes, r, y, mask, C.r);
+    hipLaunchKernelGGL(k_restrict, G256(C.N / 2), C.N / 2, L.aptr, L.anodes, L.type, L.doff, r, y, mask, C.r);
     amg_cycle(c, l + 1, C.r, C.x, C.y);
-    hipLaunchKernelGGL(k_prolong, G256(L.N * 3), L.N, L.agg, C.x, mask, h->over, x);
+    hipLaunchKernelGGL(k_prolong, G256(L.N), L.N, L.agg, L.type, L.doff, C.x, mask, h->over, x);
   }
   enq_spmv_arrays(c->stream, L.nchunks, L.chunk, L.rowptr, L.colidx, L.K, x, y);
   hipLaunchKernelGGL(k_smooth_next, G256(L.N), L.N, L.omega, L.minv, r, y, x);

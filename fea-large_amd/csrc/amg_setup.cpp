@@ -1,12 +1,12 @@
-// amg_setup.cpp -- topology of the aggregation hierarchy, host, once.
+// amg_setup.cpp -- topology and geometry of the aggregation hierarchy, host, once.
 #include "amg.h"
 #include <algorithm>
 
 namespace {
 
-// Greedy aggregation of the node graph (Vanek et al.): a node all of whose
+// Greedy aggregation of a graph (Vanek et al.): a vertex all of whose
 // neighbours are still free seeds an aggregate made of itself and them; the
-// rest join a neighbouring aggregate.
+// rest join the smallest neighbouring aggregate.
 void aggregate(int N, const std::vector<int> &rowptr, const std::vector<int> &colidx, std::vector<int> &agg, int &nagg)
 {
   agg.assign((size_t)N, -1);
@@ -52,73 +52,135 @@ void make_chunks(const std::vector<int> &rowptr, int N, std::vector<int> &chunk)
   chunk.push_back(N);
 }
 
+void finish_pattern(HostAmgLevel &L)
+{
+  const int N = L.N;
+  L.diag.resize((size_t)N);
+  for (int a = 0; a < N; ++a) {
+    const int *cb = L.colidx.data() + L.rowptr[a], *ce = L.colidx.data() + L.rowptr[a + 1];
+    L.diag[a] = L.rowptr[a] + (int)(std::lower_bound(cb, ce, a) - cb);
+  }
+  make_chunks(L.rowptr, N, L.chunk);
+}
+
 }  // namespace
 
-bool build_host_amg(const std::vector<int> &rowptr0, const std::vector<int> &colidx0, std::vector<HostAmgLevel> &out)
+// Level 0: one block row per mesh node ("site"), all of translation type.
+// Level l >= 1: two block rows per site (aggregate of the level above): its
+// translation and its rotation about the aggregate's centroid.
+bool build_host_amg(const std::vector<int> &rowptr0, const std::vector<int> &colidx0, const std::vector<double> &pos0,
+                    std::vector<HostAmgLevel> &out)
 {
   out.clear();
   HostAmgLevel L;
   L.N = (int)rowptr0.size() - 1;
+  L.S = L.N;
   L.rowptr = rowptr0; L.colidx = colidx0;
+  L.pos = pos0;
+  // site graph of the current level (level 0: the block pattern itself)
+  std::vector<int> sg_rowptr = rowptr0, sg_colidx = colidx0;
   for (;;) {
-    const int N = L.N;
+    const int N = L.N, S = L.S;
+    const bool paired = (N == 2 * S);                                      // false only on level 0
     for (int a = 0; a < N; ++a)
-      if (L.rowptr[a + 1] - L.rowptr[a] > FEA_CHUNK_BLOCKS) return false;     // SpMV chunk limit
-    L.diag.resize((size_t)N);
-    for (int a = 0; a < N; ++a) {
-      const int *cb = L.colidx.data() + L.rowptr[a], *ce = L.colidx.data() + L.rowptr[a + 1];
-      L.diag[a] = L.rowptr[a] + (int)(std::lower_bound(cb, ce, a) - cb);
-    }
-    make_chunks(L.rowptr, N, L.chunk);
-    if (N <= 1500 || out.size() >= 6) { L.Nc = 0; out.push_back(L); break; }
+      if (L.rowptr[a + 1] - L.rowptr[a] > FEA_CHUNK_BLOCKS) return false;  // SpMV chunk limit
+    finish_pattern(L);
+    if (N <= 1500 || out.size() >= 6) { L.Sc = 0; out.push_back(L); break; }
     int nagg = 0;
-    aggregate(N, L.rowptr, L.colidx, L.agg, nagg);
-    if (nagg * 2 > N) { L.Nc = 0; L.agg.clear(); out.push_back(L); break; }     // no longer coarsening
-    L.Nc = nagg;
-    // aggregate -> nodes
+    std::vector<int> sagg;
+    aggregate(S, sg_rowptr, sg_colidx, sagg, nagg);
+    if (nagg * 2 > S) { L.Sc = 0; out.push_back(L); break; }               // no longer coarsening
+    // coarse site graph
+    std::vector<int> c_rowptr((size_t)nagg + 1, 0), c_colidx;
+    {
+      std::vector<int> sptr((size_t)nagg + 1, 0), slist((size_t)S);
+      for (int s = 0; s < S; ++s) sptr[sagg[s] + 1]++;
+      for (int a = 0; a < nagg; ++a) sptr[a + 1] += sptr[a];
+      { std::vector<int> fill(sptr.begin(), sptr.end() - 1); for (int s = 0; s < S; ++s) slist[fill[sagg[s]]++] = s; }
+      std::vector<int> tmp;
+      std::vector<std::vector<int>> rows((size_t)nagg);
+      for (int I = 0; I < nagg; ++I) {
+        tmp.clear();
+        for (int p = sptr[I]; p < sptr[I + 1]; ++p) {
+          const int s = slist[p];
+          for (int q = sg_rowptr[s]; q < sg_rowptr[s + 1]; ++q) tmp.push_back(sagg[sg_colidx[q]]);
+        }
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        rows[I] = tmp;
+        c_rowptr[I + 1] = c_rowptr[I] + (int)tmp.size();
+      }
+      c_colidx.resize((size_t)c_rowptr[nagg]);
+      for (int I = 0; I < nagg; ++I) std::copy(rows[I].begin(), rows[I].end(), c_colidx.begin() + c_rowptr[I]);
+    }
+    bool too_wide = false;
+    for (int I = 0; I < nagg; ++I) if (2 * (c_rowptr[I + 1] - c_rowptr[I]) > FEA_CHUNK_BLOCKS) too_wide = true;
+    if (too_wide) { L.Sc = 0; out.push_back(L); break; }                    // keep this level as the coarsest
+    L.Sc = nagg;
+    // centroids, offsets
+    std::vector<double> cpos((size_t)nagg * 3, 0.0);
+    {
+      std::vector<int> cnt((size_t)nagg, 0);
+      for (int s = 0; s < S; ++s) { cnt[sagg[s]]++; for (int d = 0; d < 3; ++d) cpos[(size_t)sagg[s] * 3 + d] += L.pos[(size_t)s * 3 + d]; }
+      for (int a = 0; a < nagg; ++a) for (int d = 0; d < 3; ++d) cpos[(size_t)a * 3 + d] /= (double)cnt[a];
+    }
+    auto site_of = [&](int i) { return paired ? i / 2 : i; };
+    L.agg.resize((size_t)N); L.doff.resize((size_t)N * 3);
+    for (int i = 0; i < N; ++i) {
+      const int s = site_of(i), a = sagg[s];
+      L.agg[i] = a;
+      for (int d = 0; d < 3; ++d) L.doff[(size_t)i * 3 + d] = L.pos[(size_t)s * 3 + d] - cpos[(size_t)a * 3 + d];
+    }
     L.aptr.assign((size_t)nagg + 1, 0);
     for (int i = 0; i < N; ++i) L.aptr[L.agg[i] + 1]++;
     for (int a = 0; a < nagg; ++a) L.aptr[a + 1] += L.aptr[a];
     L.anodes.resize((size_t)N);
     { std::vector<int> fill(L.aptr.begin(), L.aptr.end() - 1); for (int i = 0; i < N; ++i) L.anodes[fill[L.agg[i]]++] = i; }
-    // coarse pattern
-    HostAmgLevel C;
-    C.N = nagg;
-    C.rowptr.assign((size_t)nagg + 1, 0);
-    std::vector<int> tmp;
-    std::vector<std::vector<int>> rows((size_t)nagg);
-    for (int I = 0; I < nagg; ++I) {
-      tmp.clear();
-      for (int p = L.aptr[I]; p < L.aptr[I + 1]; ++p) {
-        const int i = L.anodes[p];
-        for (int q = L.rowptr[i]; q < L.rowptr[i + 1]; ++q) tmp.push_back(L.agg[L.colidx[q]]);
-      }
-      std::sort(tmp.begin(), tmp.end());
-      tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-      rows[I] = tmp;
-      C.rowptr[I + 1] = C.rowptr[I] + (int)tmp.size();
-    }
-    C.colidx.resize((size_t)C.rowptr[nagg]);
-    for (int I = 0; I < nagg; ++I) std::copy(rows[I].begin(), rows[I].end(), C.colidx.begin() + C.rowptr[I]);
-    // which fine blocks sum into which coarse block
-    const int nnzb = L.rowptr[N], nnzc = C.rowptr[nagg];
+    // fine blocks -> coarse site pair
+    const int nnzb = L.rowptr[N], npair = c_rowptr[nagg];
     std::vector<int> cmap((size_t)nnzb);
     L.cbrow.resize((size_t)nnzb);
     for (int i = 0; i < N; ++i) {
       const int I = L.agg[i];
-      const int *cb = C.colidx.data() + C.rowptr[I], *ce = C.colidx.data() + C.rowptr[I + 1];
+      const int *cb = c_colidx.data() + c_rowptr[I], *ce = c_colidx.data() + c_rowptr[I + 1];
       for (int q = L.rowptr[i]; q < L.rowptr[i + 1]; ++q) {
-        cmap[q] = C.rowptr[I] + (int)(std::lower_bound(cb, ce, L.agg[L.colidx[q]]) - cb);
+        cmap[q] = c_rowptr[I] + (int)(std::lower_bound(cb, ce, L.agg[L.colidx[q]]) - cb);
         L.cbrow[q] = i;
       }
     }
-    L.cbptr.assign((size_t)nnzc + 1, 0);
+    L.cbptr.assign((size_t)npair + 1, 0);
     for (int q = 0; q < nnzb; ++q) L.cbptr[cmap[q] + 1]++;
-    for (int k = 0; k < nnzc; ++k) L.cbptr[k + 1] += L.cbptr[k];
+    for (int k = 0; k < npair; ++k) L.cbptr[k + 1] += L.cbptr[k];
     L.cblist.resize((size_t)nnzb);
     { std::vector<int> fill(L.cbptr.begin(), L.cbptr.end() - 1); for (int q = 0; q < nnzb; ++q) L.cblist[fill[cmap[q]]++] = q; }
+    // coarse level: two block rows per site, (translation, rotation)
+    HostAmgLevel C;
+    C.S = nagg; C.N = 2 * nagg;
+    C.pos = cpos;
+    C.type.resize((size_t)C.N);
+    C.rowptr.assign((size_t)C.N + 1, 0);
+    for (int I = 0; I < nagg; ++I) {
+      const int len = c_rowptr[I + 1] - c_rowptr[I];
+      C.type[2 * I] = 0; C.type[2 * I + 1] = 1;
+      C.rowptr[2 * I + 1] = C.rowptr[2 * I] + 2 * len;
+      C.rowptr[2 * I + 2] = C.rowptr[2 * I + 1] + 2 * len;
+    }
+    C.colidx.resize((size_t)C.rowptr[C.N]);
+    L.kpair.resize(C.colidx.size()); L.ksr.resize(C.colidx.size());
+    for (int I = 0; I < nagg; ++I)
+      for (int sg = 0; sg < 2; ++sg) {
+        const int base = C.rowptr[2 * I + sg];
+        for (int t = 0; t < c_rowptr[I + 1] - c_rowptr[I]; ++t)
+          for (int rho = 0; rho < 2; ++rho) {
+            const int k = base + 2 * t + rho;
+            C.colidx[k] = 2 * c_colidx[c_rowptr[I] + t] + rho;
+            L.kpair[k] = c_rowptr[I] + t;
+            L.ksr[k] = (uint8_t)(sg * 2 + rho);
+          }
+      }
     out.push_back(L);
     L = C;
+    sg_rowptr.swap(c_rowptr); sg_colidx.swap(c_colidx);
   }
   return out.size() >= 2;
 }

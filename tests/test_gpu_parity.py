@@ -188,6 +188,45 @@ def test_linear_solve_matches_direct_solver(solver):
     s.close()
 
 
+def test_multigrid_preconditioner_same_solution_fewer_iterations():
+    """feahip_set_preconditioner(1): PCG with the aggregation-multigrid W-cycle
+    (rigid-body coarse space).  Same linear system, same stop test: the
+    solution is the direct solver's within 1e-10 and the iteration count drops
+    well below block-Jacobi's; a whole Newton solve lands on the same nodes."""
+    deck = mesh.bar_deck(dims=(6, 36, 6))
+    s, o = make_pair(deck)
+    for obj in (s, o):
+        obj.update_nodes_with_bc(1.0)
+    o.update_state(); o.create_stiffness(); o.create_residual_forces(); o.apply_prescribed_bc(0.0)
+    s.create_stiffness_and_residual(); s.apply_prescribed_bc(0.0)
+    o.solve_slae(feahip.CHOLESKY)
+    it_bj, _ = s.solve_slae(feahip.PCG_ILU, 1e-15, 20000)
+    s.set_preconditioner(1)
+    it_mg, res = s.solve_slae(feahip.PCG_ILU, 1e-15, 20000)
+    assert res < 1e-14 and 0 < it_mg < 0.6 * it_bj
+    assert rel(s.solution(), o.solution()) < U_TOL
+    cd = np.concatenate([[3 * n + j for j in range(3) if t & (1 << j)] for n, t in zip(deck.presc_node, deck.presc_type)])
+    assert np.all(s.solution()[cd] == 0)
+    # plain CG ignores the setting (the reference's CG is unpreconditioned)
+    it_cg, _ = s.solve_slae(feahip.CG, 1e-15, 20000)
+    assert it_cg > it_bj
+    s.close()
+    deck = mesh.bar_deck(dims=(6, 36, 6), load_increments_count=1, max_newton_count=30)
+    a, b = feahip.FeaSolver(deck), feahip.FeaSolver(deck)
+    b.set_preconditioner(1)
+    ra = a.solve(solver_type=feahip.PCG_ILU, solver_tolerance=1e-15)
+    rb = b.solve(solver_type=feahip.PCG_ILU, solver_tolerance=1e-15)
+    assert ra[0] == rb[0] == 1 and list(ra[1]) == list(rb[1])
+    assert rel(b.nodes() - deck.nodes, a.nodes() - deck.nodes) < U_TOL
+    with pytest.raises(feahip.FeaHipError):
+        a.set_preconditioner(7)
+    a.close(); b.close()
+    tiny = feahip.FeaSolver(mesh.bar_deck(dims=(2, 2, 2)))
+    with pytest.raises(feahip.FeaHipError, match="multigrid"):     # nothing to coarsen: refused, not silently Jacobi
+        tiny.set_preconditioner(1)
+    tiny.close()
+
+
 def test_zero_rhs_solves_to_zero():
     deck = mesh.bar_deck(dims=(2, 2, 2))
     s = feahip.FeaSolver(deck)
