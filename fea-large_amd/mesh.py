@@ -127,6 +127,53 @@ def bar_deck(n=None, dims=None, quadratic=False, recipe="clamped", model=MODEL_C
                 presc_values=vals, **kw)
 
 
+def cylinder_deck(nr, nt, nz, quadratic=False, ri=1.0, ro=2.0, zlo=-8.0, zhi=8.0, du=None,
+                  model=None, gauss=None, **kw):
+    """BASELINE.json configs[3]: the Lame problem's hollow cylinder (dimensions
+    of exact-solutions/lame/lame_small.m:8-14: r in [1,2], z in [-8,8]) as a
+    Kuhn block in (r, axial, theta) mapped to (r cos t, -r sin t, axial) --
+    the sign keeps every signed volume positive -- and closed in theta.
+    Node numbering: r fastest, then theta, axial slowest, so a contiguous id
+    range is a slab along the axis (the row shard).  TET10 mid-side nodes are
+    mapped like the vertices (curved edges).  Boundary conditions: the inner
+    surface moves radially by `du` per increment (types 1|2), both end faces
+    keep their axial coordinate (type 4), the outer surface is free."""
+    from feahip import MODEL_A5
+    if model is None:
+        model = MODEL_A5
+    if nt < 3:
+        raise ValueError("need at least 3 cells around the cylinder")
+    pn, pe = kuhn_block(nr, nz, nt, quadratic, origin=(ri, zlo, 0.0), size=(ro - ri, zhi - zlo, 2.0 * math.pi))
+    m = 2 if quadratic else 1
+    gx, gy, gz = m * nr + 1, m * nz + 1, m * nt + 1
+    ids = np.arange(gx * gy * gz)
+    i, k, j = ids % gx, (ids // gx) % gz, ids // (gx * gz)
+    keep = k < gz - 1
+    new_id = np.full(len(ids), -1, dtype=np.int64)
+    new_id[keep] = np.arange(int(keep.sum()))
+    seam = ~keep                                        # theta = 2 pi is theta = 0
+    new_id[seam] = new_id[(j[seam] * gz + 0) * gx + i[seam]]
+    elements = new_id[pe].astype(np.int32)
+    r, ax, th = pn[keep, 0], pn[keep, 1], pn[keep, 2]
+    nodes = np.stack([r * np.cos(th), -r * np.sin(th), ax], axis=1)
+    if du is None:
+        du = 0.05 * min(1.0, 4.0 * (ro - ri) / nr)
+    inner = i[keep] == 0
+    ends = (j[keep] == 0) | (j[keep] == gy - 1)
+    sel = np.nonzero(inner | ends)[0].astype(np.int32)
+    types = (np.where(inner[sel], 3, 0) | np.where(ends[sel], 4, 0)).astype(np.int32)
+    vals = np.zeros((len(sel), 3))
+    rin = np.hypot(nodes[sel, 0], nodes[sel, 1])
+    vals[:, 0] = np.where(inner[sel], du * nodes[sel, 0] / rin, 0.0)
+    vals[:, 1] = np.where(inner[sel], du * nodes[sel, 1] / rin, 0.0)
+    if gauss is None:
+        gauss = 5 if quadratic else 1
+    kw.setdefault("solver_type", CG)
+    return Deck(model=model, parameters=[100.0, 100.0], ele_type=TETRAHEDRA10 if quadratic else TETRAHEDRA4,
+                gauss_nodes_count=gauss, nodes=nodes, elements=elements, presc_node=sel, presc_type=types,
+                presc_values=vals, **kw)
+
+
 def neohookean_lateral_stretch(k1, lam=100.0, mu=100.0):
     """k2 of the uniaxial state: root of mu(k2^2-1)+lam ln(k1 k2^2) = 0
     (exact-solutions/uniaxial/uniaxial_neohookean_bonet.m:20-26)."""

@@ -266,6 +266,31 @@ def test_newton_a5_deck_matches_oracle(decks_dir):
     s.close()
 
 
+@pytest.mark.parametrize("quadratic", [False, True])
+def test_lame_cylinder_a5(quadratic):
+    """BASELINE configs[3]: mapped, theta-periodic Kuhn block of the Lame
+    cylinder, model A5, mixed boundary types (3, 4, 7).  Assembly in the
+    bumped state and one load increment of Newton against the oracle; the
+    small-strain Lame answer itself is pinned on the oracle in
+    test_oracle_closed_form.py."""
+    deck = mesh.cylinder_deck(2, 12, 2, quadratic=quadratic, zlo=0.0, zhi=1.0, du=0.01, load_increments_count=1,
+                              max_newton_count=20, desired_tolerance=1e-16, modified_newton=False)
+    s, o = make_pair(deck)
+    for obj in (s, o):
+        obj.update_nodes_with_bc(1.0)
+    check_assembly(s, o)
+    s.close(); o.close()
+    s, o, (sd, sits, stol), (od, oits, otol) = run_newton_both(deck, 1, False)
+    assert sd == od == 1 and list(sits[:1]) == list(oits[:1])
+    du_s, du_o = s.nodes() - deck.nodes, o.nodes() - deck.nodes
+    assert rel(du_s, du_o) < U_TOL
+    r = np.hypot(deck.nodes[:, 0], deck.nodes[:, 1])
+    ur = (du_s[:, 0] * deck.nodes[:, 0] + du_s[:, 1] * deck.nodes[:, 1]) / r
+    assert np.abs(ur[np.abs(r - 1.0) < 1e-9] - 0.01).max() < 1e-15          # prescribed exactly
+    assert 0.5 * 0.01 < ur[np.abs(r - 2.0) < 1e-9].mean() < 0.8 * 0.01      # Lame: 2/3 at small strain
+    s.close(); o.close()
+
+
 def test_full_newton_tet4_patch_test_closed_form():
     """Rotation-free uniaxial recipe on linear tets: the Neo-Hookean closed
     form of exact-solutions/uniaxial/uniaxial_neohookean_bonet.m is the exact

@@ -92,3 +92,29 @@ def test_modified_newton_iteration_counts_on_clamped_deck(decks_dir):
     assert list(its2) == [13, 12]
     assert np.abs(tol - tol2).max() < 1e-11
     assert np.abs(o.nodes() - o2.nodes()).max() < 1e-12
+
+
+def test_lame_cylinder_small_strain_matches_lame_solution():
+    """BASELINE configs[3]: the thick-walled cylinder of exact-solutions/lame
+    (r in [1,2], plane strain: end faces keep their axial coordinate), inner
+    surface pushed out by a small d, outer surface free, model A5.  In the
+    small-strain limit u(r) = A r + B / r with sigma_rr(r_o) = 0 and
+    u(r_i) = d: for lambda = mu, B = 2 A r_o^2, A = d / 9, so u(r_o) = 2 d / 3
+    and u(1.5) = (1.5 + 16/3) d / 9.  Quadratic tets on a 2 x 16 x 1 mapped
+    Kuhn block reach that within 1 %."""
+    import mesh
+    d = 1e-4
+    deck = mesh.cylinder_deck(2, 16, 1, quadratic=True, zlo=0.0, zhi=0.5, du=d, load_increments_count=1,
+                              max_newton_count=6, desired_tolerance=1e-24, modified_newton=False)
+    o = OracleSolver(deck)
+    done, its, tol = o.solve(1, 6, False, 1e-24, feahip.CHOLESKY)
+    assert done == 1
+    u = o.nodes() - deck.nodes
+    r = np.hypot(deck.nodes[:, 0], deck.nodes[:, 1])
+    ur = (u[:, 0] * deck.nodes[:, 0] + u[:, 1] * deck.nodes[:, 1]) / r
+    assert np.abs(u[:, 2]).max() < 2e-3 * d        # plane strain (mid-plane nodes drift by the mesh's asymmetry only)
+    for radius, expect in ((1.0, d), (1.5, (1.5 + 8 / 1.5) * d / 9), (2.0, 2 * d / 3)):
+        sel = np.abs(r - radius) < 1e-9
+        assert sel.sum() >= 32
+        assert np.abs(ur[sel] - expect).max() < 0.01 * d, (radius, ur[sel].min(), ur[sel].max(), expect)
+    o.close()
