@@ -27,23 +27,29 @@ __device__ __forceinline__ void cross3(const double *d, double a0, double a1, do
 {
   o0 = d[1] * a2 - d[2] * a1; o1 = d[2] * a0 - d[0] * a2; o2 = d[0] * a1 - d[1] * a0;
 }
-__global__ void k_galerkin(int nnzc, const int *kpair, const uint8_t *ksr, const int *cbptr, const int *cblist,
+__global__ void k_galerkin(int npair, const int *prow, const int *crowptr, const int *cbptr, const int *cblist,
                            const double *Kf, double *Kc, const int *cbrow, const int *colidx_f, const uint8_t *type_f,
                            const double *doff, const uint8_t *mask)
 {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nnzc) return;
-  const int kp = kpair[k], sg = ksr[k] >> 1, rho = ksr[k] & 1;
-  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // one thread per aggregate pair (I, J): its four coarse blocks (kind s of I, kind r of J) from one pass over the fine blocks
+  const int kp = blockIdx.x * blockDim.x + threadIdx.x;
+  if (kp >= npair) return;
+  const int I = prow[kp];
+  const int base0 = crowptr[2 * I], base1 = crowptr[2 * I + 1];
+  const int t = kp - base0 / 4;                 // position of J in I's aggregate row (the site graph has a quarter of the blocks)
+  double acc[4][9];
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+#pragma unroll
+    for (int q = 0; q < 9; ++q) acc[w][q] = 0.0;
   for (int p = cbptr[kp]; p < cbptr[kp + 1]; ++p) {
     const int q = cblist[p];
     const int i = cbrow[q], j = colidx_f[q];
     const int ti = type_f ? type_f[i] : 0, tj = type_f ? type_f[j] : 0;
-    if ((ti == 1 && sg == 0) || (tj == 1 && rho == 0)) continue;
     double m[9];
     const double *bq = Kf + (size_t)q * 9;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) m[t] = bq[t];
+    for (int e = 0; e < 9; ++e) m[e] = bq[e];
     if (mask) {
 #pragma unroll
       for (int a = 0; a < 3; ++a)
@@ -51,22 +57,41 @@ __global__ void k_galerkin(int nnzc, const int *kpair, const uint8_t *ksr, const
         for (int bb = 0; bb < 3; ++bb)
           if (mask[3 * i + a] || mask[3 * j + bb]) m[3 * a + bb] = 0.0;
     }
-    if (ti == 0 && sg == 1) {
+    double ml[9];                                // left factor of the rotation kind: R(d_i)' m, or m for a rotation row
+#pragma unroll
+    for (int e = 0; e < 9; ++e) ml[e] = m[e];
+    if (ti == 0) {
       const double *d = doff + (size_t)i * 3;
 #pragma unroll
-      for (int cc = 0; cc < 3; ++cc) cross3(d, m[cc], m[3 + cc], m[6 + cc], m[cc], m[3 + cc], m[6 + cc]);
+      for (int cc = 0; cc < 3; ++cc) cross3(d, m[cc], m[3 + cc], m[6 + cc], ml[cc], ml[3 + cc], ml[6 + cc]);
     }
-    if (tj == 0 && rho == 1) {
-      const double *d = doff + (size_t)j * 3;
+    const double *dj = doff + (size_t)j * 3;
 #pragma unroll
-      for (int r = 0; r < 3; ++r) cross3(d, m[3 * r], m[3 * r + 1], m[3 * r + 2], m[3 * r], m[3 * r + 1], m[3 * r + 2]);
+    for (int sg = 0; sg < 2; ++sg) {
+      if (sg == 0 && ti == 1) continue;          // a rotation row has no translation part
+      const double *x = sg == 0 ? m : ml;
+      if (tj == 0) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) acc[sg * 2][e] += x[e];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          double c0, c1, c2;
+          cross3(dj, x[3 * r], x[3 * r + 1], x[3 * r + 2], c0, c1, c2);
+          acc[sg * 2 + 1][3 * r] += c0; acc[sg * 2 + 1][3 * r + 1] += c1; acc[sg * 2 + 1][3 * r + 2] += c2;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) acc[sg * 2 + 1][e] += x[e];
+      }
     }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] += m[t];
   }
-  double *o = Kc + (size_t)k * 9;
+  const int k[4] = {base0 + 2 * t, base0 + 2 * t + 1, base1 + 2 * t, base1 + 2 * t + 1};
 #pragma unroll
-  for (int t = 0; t < 9; ++t) o[t] = acc[t];
+  for (int w = 0; w < 4; ++w) {
+    double *o = Kc + (size_t)k[w] * 9;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) o[e] = acc[w][e];
+  }
 }
 
 // inverse of the diagonal 3x3 blocks; a singular block (aggregate made of
@@ -114,28 +139,36 @@ __global__ void k_smooth_next(int N, double omega, const double *minv, const dou
 
 // r_c = P' (r - K x): translation row of aggregate A = sum of the residuals of
 // its translation rows, rotation row = sum of their moments d x res plus the
-// residuals of its rotation rows; members in list order
-__global__ void k_restrict(int nagg, const int *aptr, const int *anodes, const uint8_t *type_f, const double *doff,
-                           const double *r, const double *y, const uint8_t *mask, double *rc)
+// residuals of its rotation rows.  Sixteen lanes share an aggregate: member
+// p goes to lane p mod 16, the six partial sums meet in a fixed butterfly
+// (deterministic), so the member gathers of one aggregate are in flight together.
+__global__ __launch_bounds__(256)
+void k_restrict(int nagg, const int *aptr, const int *anodes, const uint8_t *type_f, const double *doff,
+                const double *r, const double *y, const uint8_t *mask, double *rc)
 {
-  const int A = blockIdx.x * blockDim.x + threadIdx.x;
-  if (A >= nagg) return;
-  double t0 = 0, t1 = 0, t2 = 0, w0 = 0, w1 = 0, w2 = 0;
-  for (int p = aptr[A]; p < aptr[A + 1]; ++p) {
-    const int i = anodes[p];
-    const size_t k = (size_t)i * 3;
-    double a0 = r[k] - y[k], a1 = r[k + 1] - y[k + 1], a2 = r[k + 2] - y[k + 2];
-    if (mask) { if (mask[k]) a0 = 0; if (mask[k + 1]) a1 = 0; if (mask[k + 2]) a2 = 0; }
-    if (type_f && type_f[i]) { w0 += a0; w1 += a1; w2 += a2; }
-    else {
-      t0 += a0; t1 += a1; t2 += a2;
-      double m0, m1, m2;
-      cross3(doff + k, a0, a1, a2, m0, m1, m2);
-      w0 += m0; w1 += m1; w2 += m2;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int A = gid >> 4, sub = gid & 15;
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  if (A < nagg) {
+    for (int p = aptr[A] + sub; p < aptr[A + 1]; p += 16) {
+      const int i = anodes[p];
+      const size_t k = (size_t)i * 3;
+      double a0 = r[k] - y[k], a1 = r[k + 1] - y[k + 1], a2 = r[k + 2] - y[k + 2];
+      if (mask) { if (mask[k]) a0 = 0; if (mask[k + 1]) a1 = 0; if (mask[k + 2]) a2 = 0; }
+      if (type_f && type_f[i]) { s[3] += a0; s[4] += a1; s[5] += a2; }
+      else {
+        s[0] += a0; s[1] += a1; s[2] += a2;
+        double m0, m1, m2;
+        cross3(doff + k, a0, a1, a2, m0, m1, m2);
+        s[3] += m0; s[4] += m1; s[5] += m2;
+      }
     }
   }
-  double *o = rc + (size_t)A * 6;
-  o[0] = t0; o[1] = t1; o[2] = t2; o[3] = w0; o[4] = w1; o[5] = w2;
+#pragma unroll
+  for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+    for (int q = 0; q < 6; ++q) s[q] += __shfl_xor(s[q], w, 16);
+  if (A < nagg && sub < 6) rc[(size_t)A * 6 + sub] = s[sub];
 }
 
 // x += over * P x_c : translation row i gets t + w x d_i, rotation row gets w
@@ -174,12 +207,24 @@ __global__ void k_fill_pattern(int n, double *v)
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) v[t] = 1.0 + 0.37 * (double)((t * 2654435761u) >> 24) / 256.0;      // fixed pseudo-random start
 }
-__global__ void k_norm2_serial(int n, const double *v, double *out)
+// |v|^2 in two stages with a fixed grid and order (deterministic)
+__global__ __launch_bounds__(256)
+void k_norm2_partial(int n, const double *v, double *part)
 {
-  // one block, fixed order: deterministic
   __shared__ double s[256];
   double a = 0;
-  for (int i = threadIdx.x; i < n; i += 256) a += v[i] * v[i];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) a += v[i] * v[i];
+  s[threadIdx.x] = a;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w]; __syncthreads(); }
+  if (threadIdx.x == 0) part[blockIdx.x] = s[0];
+}
+__global__ __launch_bounds__(256)
+void k_norm2_final(int nparts, const double *part, double *out)
+{
+  __shared__ double s[256];
+  double a = 0;
+  for (int i = threadIdx.x; i < nparts; i += 256) a += part[i];
   s[threadIdx.x] = a;
   __syncthreads();
   for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w]; __syncthreads(); }
@@ -230,6 +275,7 @@ int amg_create(feahip_ctx *c)
   c->amg = h;
   { const char *e = getenv("FEAHIP_AMG_GAMMA"); if (e) h->gamma = atoi(e); }
   { const char *e = getenv("FEAHIP_AMG_OVER"); if (e) h->over = atof(e); }
+  { const char *e = getenv("FEAHIP_AMG_GAMMA_FROM"); if (e) h->gamma_from = atoi(e); }
   { const char *e = getenv("FEAHIP_AMG_SWEEPS"); if (e) h->coarse_sweeps = atoi(e); }
   int rc;
   h->lv.resize(hl.size());
@@ -260,8 +306,7 @@ int amg_create(feahip_ctx *c)
       if ((rc = up(c, &L.anodes, S.anodes, h->bytes))) return rc;
       if ((rc = up(c, &L.cbptr, S.cbptr, h->bytes))) return rc;
       if ((rc = up(c, &L.cblist, S.cblist, h->bytes))) return rc;
-      if ((rc = up(c, &L.kpair, S.kpair, h->bytes))) return rc;
-      if ((rc = up(c, &L.ksr, S.ksr, h->bytes))) return rc;
+      if ((rc = up(c, &L.prow, S.prow, h->bytes))) return rc;
       if ((rc = up(c, &L.cbrow, S.cbrow, h->bytes))) return rc;
     }
   }
@@ -275,7 +320,7 @@ void amg_destroy(feahip_ctx *c)
   AmgHierarchy *h = H(c);
   if (!h) return;
   for (AmgLevel &L : h->lv) {
-    void *own[] = {L.minv, L.agg, L.doff, L.aptr, L.anodes, L.cbptr, L.cblist, L.kpair, L.ksr, L.cbrow, L.r, L.x, L.y, L.type};
+    void *own[] = {L.minv, L.agg, L.doff, L.aptr, L.anodes, L.cbptr, L.cblist, L.prow, L.cbrow, L.r, L.x, L.y, L.type};
     for (void *p : own) if (p) (void)hipFree(p);
     if (L.owns_matrix) { void *m[] = {L.rowptr, L.colidx, L.diag, L.chunk, L.K}; for (void *p : m) if (p) (void)hipFree(p); }
   }
@@ -297,7 +342,7 @@ static int amg_numeric(feahip_ctx *c)
     hipLaunchKernelGGL(k_block_inverse, G256(L.N), L.N, L.diag, L.K, L.minv);
     if (L.Nc > 0) {
       AmgLevel &C = h->lv[l + 1];
-      hipLaunchKernelGGL(k_galerkin, G256(C.nnzb), C.nnzb, L.kpair, L.ksr, L.cbptr, L.cblist, L.K, C.K, L.cbrow, L.colidx,
+      hipLaunchKernelGGL(k_galerkin, G256(C.nnzb / 4), C.nnzb / 4, L.prow, C.rowptr, L.cbptr, L.cblist, L.K, C.K, L.cbrow, L.colidx,
                          L.type, L.doff, l == 0 ? c->d_dofmask : (const uint8_t *)nullptr);
     }
     // lambda_max(D^-1 K) by a few power iterations -> omega = 4 / (3 lambda_max)
@@ -308,7 +353,9 @@ static int amg_numeric(feahip_ctx *c)
     for (int it = 0; it < 8; ++it) {
       enq_spmv_arrays(c->stream, L.nchunks, L.chunk, L.rowptr, L.colidx, L.K, v, y);
       hipLaunchKernelGGL(k_apply_minv, G256(L.N), L.N, L.minv, y, v);
-      hipLaunchKernelGGL(k_norm2_serial, dim3(1), dim3(256), 0, c->stream, n, v, c->d_scal + 12);
+      const int nb = n >= 256 * 1024 ? 1024 : (n + 255) / 256;
+      hipLaunchKernelGGL(k_norm2_partial, dim3(nb), dim3(256), 0, c->stream, n, v, c->d_part);
+      hipLaunchKernelGGL(k_norm2_final, dim3(1), dim3(256), 0, c->stream, nb, c->d_part, c->d_scal + 12);
       double nrm2 = 0;
       FEA_HIP_CHECK(c, hipMemcpyAsync(&nrm2, c->d_scal + 12, sizeof(double), hipMemcpyDeviceToHost, c->stream));
       FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
@@ -343,10 +390,10 @@ static void amg_cycle(feahip_ctx *c, int l, const double *r, double *x, double *
     return;
   }
   AmgLevel &C = h->lv[l + 1];
-  const int gamma = (l == 0) ? 1 : h->gamma;
+  const int gamma = (l < h->gamma_from) ? 1 : h->gamma;
   for (int g = 0; g < gamma; ++g) {
     enq_spmv_arrays(c->stream, L.nchunks, L.chunk, L.rowptr, L.colidx, L.K, x, y);
-    hipLaunchKernelGGL(k_restrict, G256(C.N / 2), C.N / 2, L.aptr, L.anodes, L.type, L.doff, r, y, mask, C.r);
+    hipLaunchKernelGGL(k_restrict, G256((C.N / 2) * 16), C.N / 2, L.aptr, L.anodes, L.type, L.doff, r, y, mask, C.r);
     amg_cycle(c, l + 1, C.r, C.x, C.y);
     hipLaunchKernelGGL(k_prolong, G256(L.N), L.N, L.agg, L.type, L.doff, C.x, mask, h->over, x);
   }

@@ -166,7 +166,8 @@ bool build_host_amg(const std::vector<int> &rowptr0, const std::vector<int> &col
       C.rowptr[2 * I + 2] = C.rowptr[2 * I + 1] + 2 * len;
     }
     C.colidx.resize((size_t)C.rowptr[C.N]);
-    L.kpair.resize(C.colidx.size()); L.ksr.resize(C.colidx.size());
+    L.prow.resize((size_t)npair);
+    for (int I = 0; I < nagg; ++I) for (int t = c_rowptr[I]; t < c_rowptr[I + 1]; ++t) L.prow[t] = I;
     for (int I = 0; I < nagg; ++I)
       for (int sg = 0; sg < 2; ++sg) {
         const int base = C.rowptr[2 * I + sg];
@@ -174,8 +175,6 @@ bool build_host_amg(const std::vector<int> &rowptr0, const std::vector<int> &col
           for (int rho = 0; rho < 2; ++rho) {
             const int k = base + 2 * t + rho;
             C.colidx[k] = 2 * c_colidx[c_rowptr[I] + t] + rho;
-            L.kpair[k] = c_rowptr[I] + t;
-            L.ksr[k] = (uint8_t)(sg * 2 + rho);
           }
       }
     out.push_back(L);
