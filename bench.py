@@ -179,7 +179,7 @@ def main():
                                f"no collective in assembly"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, world),
-                     "kernel": "k_assemble_visit" if not args.quadratic else "k_assemble_rowowner",
+                     "kernel": "k_assemble_visit" if not args.quadratic else "k_assemble_quad",
                      "algorithmic_bytes_per_launch": B},
         "extras": extras,
     }

@@ -136,6 +136,18 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
       }
     }
   }
+  if (npe == 10) {
+    HostQuad hq;
+    build_host_quad(n_nodes, n_elems, npe, elements, hp, hq);
+    if (hq.ok) {
+      if ((rc = dev_upload(c, &c->d_qdesc, hq.desc.data(), hq.desc.size()))) return rc;
+      if ((rc = dev_upload(c, &c->d_qelem, hq.qelem.data(), hq.qelem.size()))) return rc;
+      if ((rc = dev_upload(c, &c->d_qpair, hq.qpair.data(), hq.qpair.size()))) return rc;
+      if ((rc = dev_upload(c, &c->d_qnode, hq.qnode.data(), hq.qnode.size()))) return rc;
+      c->have_quad = true;
+      c->quad_bytes = (long long)(hq.desc.size() * sizeof(QuadDesc) + hq.qelem.size() * 4 + hq.qpair.size() * 4 + hq.qnode.size() * 4);
+    }
+  }
   if ((rc = dev_zeros(c, &c->d_K, (size_t)c->nnzb * 9 + 2))) return rc;   // +2: the SpMV reads aligned 80-byte windows
   if ((rc = dev_zeros(c, &c->d_f, (size_t)c->ndof))) return rc;
   if ((rc = dev_zeros(c, &c->d_u, (size_t)c->ndof))) return rc;
@@ -198,7 +210,7 @@ extern "C" void feahip_destroy(feahip_ctx *c)
 {
   if (!c) return;
   void *ptrs[] = {c->d_table, c->d_conn, c->d_X0, c->d_x, c->d_rowptr, c->d_colidx, c->d_K, c->d_Kstash,
-                  c->d_incptr, c->d_inc, c->d_incslot, c->d_chunk, c->d_diag, c->d_pdesc, c->d_pnode, c->d_pelem, c->d_pent, c->d_pbptr, c->d_vdesc, c->d_vnode, c->d_vrec, c->d_pairdesc, c->d_prec, c->d_f, c->d_u, c->d_r, c->d_p,
+                  c->d_incptr, c->d_inc, c->d_incslot, c->d_chunk, c->d_diag, c->d_pdesc, c->d_pnode, c->d_pelem, c->d_pent, c->d_pbptr, c->d_vdesc, c->d_vnode, c->d_vrec, c->d_pairdesc, c->d_prec, c->d_qdesc, c->d_qelem, c->d_qpair, c->d_qnode, c->d_f, c->d_u, c->d_r, c->d_p,
                   c->d_q, c->d_minv, c->d_part, c->d_scal, c->d_flag, c->d_cdof, c->d_cval,
                   c->d_dofmask, c->d_F, c->d_S};
   for (void *p : ptrs)
@@ -225,7 +237,7 @@ extern "C" int feahip_sync(feahip_ctx *c)
 extern "C" int feahip_set_assembly(feahip_ctx *c, int strategy)
 {
   CTX_GUARD(c);
-  if (strategy < FEAHIP_ASM_AUTO || strategy > FEAHIP_ASM_PIPELINED) { c->err = "unknown assembly strategy"; return FEAHIP_EINVAL; }
+  if (strategy < FEAHIP_ASM_AUTO || strategy > FEAHIP_ASM_SHARED) { c->err = "unknown assembly strategy"; return FEAHIP_EINVAL; }
   c->strategy = strategy;
   return FEAHIP_OK;
 }
@@ -598,7 +610,8 @@ extern "C" int feahip_sizes(feahip_ctx *c, long long *o)
   if (!c || !o) return FEAHIP_EINVAL;
   o[0] = c->N; o[1] = c->E; o[2] = c->npe; o[3] = c->G; o[4] = c->nnzb; o[5] = c->nchunks;
   // bytes of the maps the default assembly kernel reads besides the algorithmic inputs
-  o[6] = c->have_visits ? c->visit_bytes + (long long)(c->N + 1) * 8 : c->aux_bytes;
+  o[6] = c->have_visits ? c->visit_bytes + (long long)(c->N + 1) * 8
+       : c->have_quad ? c->quad_bytes + (long long)(c->N + 1) * 8 : c->aux_bytes;
   o[7] = c->max_rowlen;
   return FEAHIP_OK;
 }

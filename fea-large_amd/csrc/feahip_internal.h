@@ -83,6 +83,11 @@ struct feahip_ctx {
   int *d_vnode = nullptr;
   uint32_t *d_vrec = nullptr;
   long long visit_bytes = 0;
+  bool have_quad = false;
+  struct QuadDesc *d_qdesc = nullptr;
+  uint32_t *d_qelem = nullptr, *d_qpair = nullptr;
+  int *d_qnode = nullptr;
+  long long quad_bytes = 0;
   bool have_pairs = false;
   struct VisitDesc *d_pairdesc = nullptr;
   uint32_t *d_prec = nullptr;
@@ -182,6 +187,28 @@ struct HostVisits {
   bool ok = false;
 };
 void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, HostVisits &out);
+// shared-state assembly of 10-node elements (kernels_quad.hip): per chunk the
+// distinct elements touching its rows and one 4-byte record per
+// (row, element, column node) pair
+#define FEA_QUAD_BLOCKS 128           // K tile of one workgroup
+#define FEA_QUAD_PAIRS 256            // pairs of a multi-row chunk (a single row may have more)
+#define FEA_QUAD_ELEMS 64             // distinct elements of a chunk (6-bit index in a pair record)
+#define FEA_QUAD_NODES 126            // coordinate tile: distinct nodes of the chunk's elements
+struct QuadDesc {                    // 40 bytes, one per chunk
+  int r0, r1, b0, nb;
+  int elem_off, nelem;               // into qelem (3 words per element)
+  int pair_off, npair;               // into qpair
+  int node_off, nnode;               // into qnode
+};
+struct HostQuad {
+  std::vector<QuadDesc> desc;
+  std::vector<int> qnode;            // global ids of the chunk's nodes
+  std::vector<uint32_t> qelem;       // per element 12 bytes: 10 chunk-local node ids (u8), flags (bit 0: its local node 0 is a row of this chunk), 0
+  std::vector<uint32_t> qpair;       // el(6) | la(4)<<6 | lb(4)<<10 | tile position(8)<<14 | local row(4)<<22 | first pair of its visit<<26
+  bool ok = false;
+};
+void build_host_quad(int N, int E, int npe, const int *conn, const HostPattern &hp, HostQuad &out);
+int launch_assemble_quad(feahip_ctx *c, bool doF);
 struct HostPairs {
   std::vector<VisitDesc> desc;       // visit_off / nvisit = first pair / pairs of the chunk
   std::vector<uint32_t> prec;        // [4 * pairs]: ids a,p,q,r | s,flags | slots p,q,r,s | 0

@@ -219,13 +219,62 @@ __device__ __forceinline__ void gp_state(const double (&xe)[NPE][3], const doubl
   s.vol = tab->w[gp] * fabs(s.detJ);
 }
 
+// Cauchy stress and tangent coefficients l1, m1 of the two material models from
+// the deformation gradient (fea_model.c:97-150; compact forms: file header).
+__device__ __forceinline__ void fd_constitutive(const double (&F)[3][3], int model, double lambda, double mu,
+                                                double (&sig)[3][3], double &l1, double &m1)
+{
+  const double Jd = fd_det3(F);
+  const double iJ = fd_rcp(Jd);
+  if (model == FEAHIP_MODEL_COMPRESSIBLE_NEOHOOKEAN) {
+    const double lnJ = log(Jd);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double b = F[i][0] * F[j][0] + F[i][1] * F[j][1] + F[i][2] * F[j][2];
+        const double d = (i == j) ? 1.0 : 0.0;
+        sig[i][j] = (mu * (b - d) + lambda * lnJ * d) * iJ;
+      }
+    l1 = lambda * iJ;
+    m1 = (mu - lambda * lnJ) * iJ;
+  } else {
+    double Sn[3][3], T[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double gij = F[0][i] * F[0][j] + F[1][i] * F[1][j] + F[2][i] * F[2][j];
+        Sn[i][j] = 0.5 * (gij - ((i == j) ? 1.0 : 0.0));
+      }
+    const double I1 = Sn[0][0] + Sn[1][1] + Sn[2][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        Sn[i][j] = (lambda * I1 * ((i == j) ? 1.0 : 0.0) + 2 * mu * Sn[i][j]) * iJ;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        T[i][j] = F[i][0] * Sn[0][j] + F[i][1] * Sn[1][j] + F[i][2] * Sn[2][j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        sig[i][j] = T[i][0] * F[j][0] + T[i][1] * F[j][1] + T[i][2] * F[j][2];
+    l1 = lambda * iJ;
+    m1 = mu * iJ;
+  }
+}
+
 // Same state for elements with many nodes (TET10), streaming the node
 // coordinates from memory inside the sums instead of holding x and X0 of all
 // nodes in registers: 120 fewer VGPRs per lane (2-3x the occupancy); the
 // re-reads of every Gauss point hit L1.
-template <int NPE>
+template <int NPE, class TAB = ElemTable>
 __device__ __forceinline__ void gp_state_stream(const double *xg, const double *X0g, const int (&nd)[NPE],
-                                                const ElemTable *tab, int gp, int model,
+                                                const TAB *tab, int gp, int model,
                                                 double lambda, double mu, GPState<NPE> &s)
 {
   double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Ji[3][3];
@@ -257,48 +306,7 @@ __device__ __forceinline__ void gp_state_stream(const double *xg, const double *
       for (int j = 0; j < 3; ++j) Fi[i][j] += s.g[k][j] * c[i];
   }
   fd_inv3(Fi, s.F, detFi);
-  const double Jd = fd_det3(s.F);
-  const double iJ = fd_rcp(Jd);
-  if (model == FEAHIP_MODEL_COMPRESSIBLE_NEOHOOKEAN) {
-    const double lnJ = log(Jd);
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const double b = s.F[i][0] * s.F[j][0] + s.F[i][1] * s.F[j][1] + s.F[i][2] * s.F[j][2];
-        const double d = (i == j) ? 1.0 : 0.0;
-        s.sig[i][j] = (mu * (b - d) + lambda * lnJ * d) * iJ;
-      }
-    s.l1 = lambda * iJ;
-    s.m1 = (mu - lambda * lnJ) * iJ;
-  } else {
-    double Sn[3][3], T[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const double gij = s.F[0][i] * s.F[0][j] + s.F[1][i] * s.F[1][j] + s.F[2][i] * s.F[2][j];
-        Sn[i][j] = 0.5 * (gij - ((i == j) ? 1.0 : 0.0));
-      }
-    const double I1 = Sn[0][0] + Sn[1][1] + Sn[2][2];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        Sn[i][j] = (lambda * I1 * ((i == j) ? 1.0 : 0.0) + 2 * mu * Sn[i][j]) * iJ;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        T[i][j] = s.F[i][0] * Sn[0][j] + s.F[i][1] * Sn[1][j] + s.F[i][2] * Sn[2][j];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        s.sig[i][j] = T[i][0] * s.F[j][0] + T[i][1] * s.F[j][1] + T[i][2] * s.F[j][2];
-    s.l1 = lambda * iJ;
-    s.m1 = mu * iJ;
-  }
+  fd_constitutive(s.F, model, lambda, mu, s.sig, s.l1, s.m1);
   s.vol = tab->w[gp] * fabs(s.detJ);
 }
 

@@ -297,7 +297,18 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
   // AUTO: row-owner visits, with LDS-staged coordinates where the maps exist (linear tets);
   // PATCH is the bitwise-reproducible variant, slower today
   if (strat == FEAHIP_ASM_AUTO)
-    strat = c->have_visits ? FEAHIP_ASM_STAGED : (rowowner_ok ? FEAHIP_ASM_ROWOWNER : FEAHIP_ASM_ATOMIC);
+    strat = c->have_visits ? FEAHIP_ASM_STAGED
+          : (c->have_quad && doK) ? FEAHIP_ASM_SHARED
+          : (rowowner_ok ? FEAHIP_ASM_ROWOWNER : FEAHIP_ASM_ATOMIC);
+  if (strat == FEAHIP_ASM_SHARED && !doK && c->have_quad) strat = rowowner_ok ? FEAHIP_ASM_ROWOWNER : FEAHIP_ASM_ATOMIC;   // residual alone: visit kernel
+  if (strat == FEAHIP_ASM_SHARED) {
+    if (!c->have_quad) {
+      c->err = "shared-state assembly needs 10-node elements whose chunks fit the LDS tiles";
+      return FEAHIP_EINVAL;
+    }
+    FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));
+    return launch_assemble_quad(c, doF);
+  }
   if (strat == FEAHIP_ASM_PAIRED) {
     if (!c->have_pairs) {
       c->err = "paired assembly needs linear tetrahedra whose chunks fit the LDS tiles";

@@ -1,0 +1,235 @@
+// kernels_quad.hip -- stiffness + residual assembly of 10-node tetrahedra
+// (the reference's element, fea_solver.c:873-883 / :887-1068 / :1072-1114)
+// with the Gauss-point state shared between the visits of a chunk.
+//
+// The generic row-owner kernel (kernels_assemble.hip) gives a lane one (row
+// node, element) visit: for a 10-node element that lane evaluates the state of
+// every Gauss point itself (10x redundantly over the element's nodes), adds
+// 9 blocks x 9 doubles to the LDS tile PER Gauss point (405 ds_add_f64 per
+// visit at G = 5), and a chunk of 2-4 rows has only ~20 visits for 64 lanes.
+// Here a workgroup of four waves owns a chunk of block rows (four, so that the
+// 37 KB of tiles below are shared by enough waves to keep the SIMDs busy: one
+// wave per chunk left 1.2 waves per SIMD waiting on their own dependent FP64
+// chains, VALU 32 % busy), and the work is cut twice:
+//   phase 1  lane <-> (element of the chunk, Gauss point): the state -- inverse
+//            Jacobian of the current configuration, stress, tangent
+//            coefficients, w|det J| -- once per chunk, into an LDS tile
+//            (structure of arrays: lane-linear writes, broadcast reads).  Node
+//            coordinates, the elements' local node ids and the shape-function
+//            table of the batch are staged in LDS first: phase 1 touches no
+//            global memory;
+//   phase 2  lane <-> (row node a, element, column node b): the spatial
+//            gradients g_a, g_b = J^-T dN from the state entry, K_ab summed
+//            over the Gauss points of the batch in registers, then 9
+//            ds_add_f64 into the wave's K tile; the 9 lanes of a visit read
+//            the same state entry.
+// Gauss points go through in batches of as many as fit 128 state entries, so
+// the 27-point rule runs in the same LDS.  The diagonal blocks come from the
+// row sums (shape functions sum to one) and the rows are streamed out: every
+// CSR value written once.
+#include "fem_device.h"
+
+struct QuadArgs {
+  int chunk0, nchunks, model, G;
+  double lambda, mu;
+  const ElemTable *tab;
+  const QuadDesc *desc;
+  const uint32_t *qelem, *qpair;
+  const int *qnode;
+  const double *X0, *x;
+  const int *rowptr, *diag;
+  double *K, *f;
+  int *bad;
+};
+
+// rows of the state tile
+#define QS_JI 0       // 9: inverse Jacobian Ji[i][m] at 3i+m   (g_a[i] = sum_m Ji[i][m] dN[m][a])
+#define QS_SIG 9      // 6: 00 01 02 11 12 22
+#define QS_L1 15
+#define QS_M1 16
+#define QS_VOL 17
+#define QS_ROWS 18
+#define QUAD_NT 256                    // threads per chunk
+#define QUAD_ENTRIES 128              // (element, Gauss point) entries per batch
+#define FEA_QUAD_BATCH_GAUSS 8        // Gauss points per batch at most (size of the table slice in LDS)
+
+template <int NPE, bool DOF>
+__global__ __launch_bounds__(QUAD_NT)
+void k_assemble_quad(QuadArgs A)
+{
+  __shared__ double sS[QS_ROWS][QUAD_ENTRIES];
+  __shared__ double sx[FEA_QUAD_NODES * 3], sX[FEA_QUAD_NODES * 3];     // current / reference coordinates of the chunk's nodes
+  __shared__ uint32_t sE[FEA_QUAD_ELEMS * 3];
+  __shared__ double sTw[FEA_QUAD_BATCH_GAUSS];                          // table slice of the batch
+  __shared__ double sTd[FEA_QUAD_BATCH_GAUSS][3][NPE];
+  __shared__ double sK[FEA_QUAD_BLOCKS * 9 + 2];
+  __shared__ double sF[FEA_CHUNK_ROWS * 3];
+  __shared__ int sRow[FEA_CHUNK_ROWS + 1];
+  __shared__ int sDiag[FEA_CHUNK_ROWS];
+  const int lane = threadIdx.x;
+  const int nwg = gridDim.x, per = (nwg + 7) >> 3;
+  const int cidx = (blockIdx.x & 7) * per + (blockIdx.x >> 3);     // XCD-contiguous chunk order (kernels_visit.hip)
+  if (cidx >= A.nchunks) return;
+  const QuadDesc d = A.desc[A.chunk0 + cidx];
+  const int nrows = d.r1 - d.r0;
+  const int odd = d.b0 & 1;
+  double *sKt = sK + odd;
+
+  for (int t = lane; t < d.nnode; t += QUAD_NT) {
+    const size_t n = (size_t)A.qnode[(size_t)d.node_off + t];
+    const double2 a0 = *reinterpret_cast<const double2 *>(A.x + n * 4), a1 = *reinterpret_cast<const double2 *>(A.x + n * 4 + 2);
+    const double2 c0 = *reinterpret_cast<const double2 *>(A.X0 + n * 4), c1 = *reinterpret_cast<const double2 *>(A.X0 + n * 4 + 2);
+    sx[t * 3] = a0.x; sx[t * 3 + 1] = a0.y; sx[t * 3 + 2] = a1.x;
+    sX[t * 3] = c0.x; sX[t * 3 + 1] = c0.y; sX[t * 3 + 2] = c1.x;
+  }
+  for (int t = lane; t < d.nelem * 3; t += QUAD_NT) sE[t] = A.qelem[(size_t)d.elem_off * 3 + t];
+  if (lane <= nrows) sRow[lane] = A.rowptr[d.r0 + lane] - d.b0;
+  if (lane < nrows) sDiag[lane] = A.diag[d.r0 + lane] - d.b0;
+  for (int t = lane; t < d.nb * 9; t += QUAD_NT) sKt[t] = 0.0;
+  if (DOF)
+    for (int t = lane; t < nrows * 3; t += QUAD_NT) sF[t] = 0.0;
+
+  const int ne = d.nelem;
+  int gb = QUAD_ENTRIES / ne;
+  gb = gb < 1 ? 1 : (gb > A.G ? A.G : gb);
+  gb = gb > FEA_QUAD_BATCH_GAUSS ? FEA_QUAD_BATCH_GAUSS : gb;
+  gb = (A.G + (A.G + gb - 1) / gb - 1) / ((A.G + gb - 1) / gb);          // same number of batches, evenly filled
+  for (int g0 = 0; g0 < A.G; g0 += gb) {
+    const int ng = (A.G - g0 < gb) ? (A.G - g0) : gb;
+    __syncthreads();                                   // the previous batch has been read
+    for (int t = lane; t < ng; t += QUAD_NT) sTw[t] = A.tab->w[g0 + t];
+    for (int t = lane; t < ng * 3 * NPE; t += QUAD_NT) (&sTd[0][0][0])[t] = A.tab->dN[g0 + t / (3 * NPE)][(t / NPE) % 3][t % NPE];
+    __syncthreads();
+    // ---- phase 1: state of (element, Gauss point) entries
+    if (lane < ne * ng) {
+      const int el = lane / ng, tg = lane % ng;
+      const uint32_t e0 = sE[el * 3], e1 = sE[el * 3 + 1], e2 = sE[el * 3 + 2];
+      const int nd[10] = {(int)(e0 & 255u), (int)((e0 >> 8) & 255u), (int)((e0 >> 16) & 255u), (int)(e0 >> 24),
+                          (int)(e1 & 255u), (int)((e1 >> 8) & 255u), (int)((e1 >> 16) & 255u), (int)(e1 >> 24),
+                          (int)(e2 & 255u), (int)((e2 >> 8) & 255u)};
+      // J = dx/dxi, M = dX/dxi (both as sum_k dN[.][k] (x) coordinates of node k)
+      double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, M[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+      for (int k = 0; k < NPE; ++k) {
+        const double xc[3] = {sx[nd[k] * 3], sx[nd[k] * 3 + 1], sx[nd[k] * 3 + 2]};
+        const double Xc[3] = {sX[nd[k] * 3], sX[nd[k] * 3 + 1], sX[nd[k] * 3 + 2]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const double dn = sTd[tg][i][k];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) { J[i][j] += dn * xc[j]; M[i][j] += dn * Xc[j]; }
+        }
+      }
+      double Ji[3][3], detJ;
+      fd_inv3(J, Ji, detJ);
+      // F^-1 = sum_k X_k (x) g_k with g_k = Ji dN_k  =>  Finv[i][j] = sum_m M[m][i] Ji[j][m]
+      double Fi[3][3], F[3][3], detFi;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Fi[i][j] = M[0][i] * Ji[j][0] + M[1][i] * Ji[j][1] + M[2][i] * Ji[j][2];
+      fd_inv3(Fi, F, detFi);
+      double sig[3][3], l1, m1;
+      fd_constitutive(F, A.model, A.lambda, A.mu, sig, l1, m1);
+      if (!(detJ > 0.0) && ((e2 >> 16) & 1u)) atomicAdd(A.bad, 1);       // once per (element, Gauss point) of the mesh
+      const bool dead = detJ == 0.0;                                      // fea_solver.c:697: no gradient then
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) sS[QS_JI + 3 * i + m][lane] = dead ? 0.0 : Ji[i][m];
+      sS[QS_SIG + 0][lane] = dead ? 0.0 : sig[0][0]; sS[QS_SIG + 1][lane] = dead ? 0.0 : sig[0][1];
+      sS[QS_SIG + 2][lane] = dead ? 0.0 : sig[0][2]; sS[QS_SIG + 3][lane] = dead ? 0.0 : sig[1][1];
+      sS[QS_SIG + 4][lane] = dead ? 0.0 : sig[1][2]; sS[QS_SIG + 5][lane] = dead ? 0.0 : sig[2][2];
+      sS[QS_L1][lane] = dead ? 0.0 : l1;
+      sS[QS_M1][lane] = dead ? 0.0 : m1;
+      sS[QS_VOL][lane] = dead ? 0.0 : sTw[tg] * fabs(detJ);
+    }
+    __syncthreads();
+    // ---- phase 2: blocks of (row node, element, column node) pairs over the batch, then into the K tile
+    for (int p0 = lane; p0 < d.npair; p0 += QUAD_NT) {
+      const uint32_t w = A.qpair[(size_t)d.pair_off + p0];
+      const int el = w & 63u, la = (w >> 6) & 15u, lb = (w >> 10) & 15u;
+      double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, fa[3] = {0, 0, 0};
+      for (int t = 0; t < ng; ++t) {
+        const int ent = el * ng + t;
+        double Ji[3][3], ga[3], gbv[3], sig[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) Ji[i][m] = sS[QS_JI + 3 * i + m][ent];
+        const double da[3] = {sTd[t][0][la], sTd[t][1][la], sTd[t][2][la]};
+        const double db[3] = {sTd[t][0][lb], sTd[t][1][lb], sTd[t][2][lb]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          ga[i] = Ji[i][0] * da[0] + Ji[i][1] * da[1] + Ji[i][2] * da[2];
+          gbv[i] = Ji[i][0] * db[0] + Ji[i][1] * db[1] + Ji[i][2] * db[2];
+        }
+        sig[0][0] = sS[QS_SIG + 0][ent]; sig[0][1] = sig[1][0] = sS[QS_SIG + 1][ent]; sig[0][2] = sig[2][0] = sS[QS_SIG + 2][ent];
+        sig[1][1] = sS[QS_SIG + 3][ent]; sig[1][2] = sig[2][1] = sS[QS_SIG + 4][ent]; sig[2][2] = sS[QS_SIG + 5][ent];
+        RowVecs rv;
+        row_vectors(ga, sig, sS[QS_L1][ent], sS[QS_M1][ent], sS[QS_VOL][ent], rv);
+        double blk[9];
+        block_row(rv, gbv, blk);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) acc[q] += blk[q];
+        if (DOF) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) fa[i] -= rv.s[i];
+        }
+      }
+      double *dst = sKt + (int)((w >> 14) & 255u) * 9;
+#pragma unroll
+      for (int q = 0; q < 9; ++q)
+        __hip_atomic_fetch_add(dst + q, acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (DOF && ((w >> 26) & 1u)) {
+        const int rl = (w >> 22) & 15u;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          __hip_atomic_fetch_add(&sF[rl * 3 + i], fa[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+  __syncthreads();
+  // K_aa = -sum_{b != a} K_ab: the diagonal block was never added to
+  for (int t = lane; t < nrows * 9; t += QUAD_NT) {
+    const int r = t / 9, q = t % 9;
+    const int kb = sRow[r], ke = sRow[r + 1], kd = sDiag[r];
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int k = kb;
+    for (; k + 3 < ke; k += 4) {
+      a0 += sKt[k * 9 + q]; a1 += sKt[(k + 1) * 9 + q]; a2 += sKt[(k + 2) * 9 + q]; a3 += sKt[(k + 3) * 9 + q];
+    }
+    for (; k < ke; ++k) a0 += sKt[k * 9 + q];
+    sKt[kd * 9 + q] = -((a0 + a1) + (a2 + a3));
+  }
+  __syncthreads();
+  double *Kd = A.K + (size_t)d.b0 * 9;
+  const int total = d.nb * 9;
+  if (odd && lane == 0) Kd[0] = sKt[0];
+  const int npair2 = (total - odd) >> 1;
+  for (int t = lane; t < npair2; t += QUAD_NT) {
+    const int j = odd + 2 * t;
+    *reinterpret_cast<double2 *>(Kd + j) = *reinterpret_cast<const double2 *>(sKt + j);
+  }
+  if (((total - odd) & 1) && lane == 0) Kd[total - 1] = sKt[total - 1];
+  if (DOF) {
+    double *fd = A.f + (size_t)d.r0 * 3;
+    for (int t = lane; t < nrows * 3; t += QUAD_NT) fd[t] = sF[t];
+  }
+}
+
+int launch_assemble_quad(feahip_ctx *c, bool doF)
+{
+  if (c->npe != 10) { c->err = "shared-state assembly is built for 10-node elements"; return FEAHIP_EINVAL; }
+  QuadArgs A;
+  A.chunk0 = c->achunk0; A.nchunks = c->nachunks_local; A.model = c->model; A.G = c->G;
+  A.lambda = c->lambda; A.mu = c->mu; A.tab = c->d_table; A.desc = c->d_qdesc; A.qelem = c->d_qelem; A.qpair = c->d_qpair;
+  A.qnode = c->d_qnode; A.X0 = c->d_X0; A.x = c->d_x; A.rowptr = c->d_rowptr; A.diag = c->d_diag;
+  A.K = c->d_K; A.f = c->d_f; A.bad = c->d_flag + 1;
+  if (c->nachunks_local <= 0) return FEAHIP_OK;
+  const dim3 grid((c->nachunks_local + 7) & ~7), blk(QUAD_NT);
+  if (doF) hipLaunchKernelGGL((k_assemble_quad<10, true>), grid, blk, 0, c->stream, A);
+  else     hipLaunchKernelGGL((k_assemble_quad<10, false>), grid, blk, 0, c->stream, A);
+  FEA_HIP_CHECK(c, hipGetLastError());
+  return FEAHIP_OK;
+}

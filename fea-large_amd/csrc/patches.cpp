@@ -528,3 +528,86 @@ void build_host_pairs(const int *conn, const HostPattern &hp, const HostVisits &
   out.npairs_total = (long long)tot;
   out.ok = true;
 }
+
+// ---------------------------------------------------------------------------
+// maps of the shared-state assembly of 10-node elements (kernels_quad.hip)
+// ---------------------------------------------------------------------------
+void build_host_quad(int N, int E, int npe, const int *conn, const HostPattern &hp, HostQuad &out)
+{
+  (void)N; (void)E;
+  out.ok = false;
+  if (hp.achunk.size() < 2 || npe != 10 || hp.max_rowlen > 255) return;
+  const int np = (int)hp.achunk.size() - 1;
+  out.desc.resize((size_t)np);
+  // sizes first (prefix sums), then fill in parallel
+  std::vector<int> nel((size_t)np, 0), nnd((size_t)np, 0);
+  par_for(np, [&](int lo, int hi) {
+    std::vector<int> el, nd;
+    for (int p = lo; p < hi; ++p) {
+      const int r0 = hp.achunk[p], r1 = hp.achunk[p + 1];
+      el.clear(); nd.clear();
+      for (int q = hp.incptr[r0]; q < hp.incptr[r1]; ++q) el.push_back((int)(hp.inc_rows[q] & 0x0FFFFFFFu));
+      std::sort(el.begin(), el.end());
+      el.erase(std::unique(el.begin(), el.end()), el.end());
+      for (int e : el) for (int k = 0; k < npe; ++k) nd.push_back(conn[(size_t)e * npe + k]);
+      std::sort(nd.begin(), nd.end());
+      nel[p] = (int)el.size();
+      nnd[p] = (int)(std::unique(nd.begin(), nd.end()) - nd.begin());
+    }
+  });
+  size_t eo = 0, po = 0, no = 0;
+  for (int p = 0; p < np; ++p) {
+    const int r0 = hp.achunk[p], r1 = hp.achunk[p + 1];
+    QuadDesc &d = out.desc[p];
+    d.r0 = r0; d.r1 = r1; d.b0 = hp.rowptr[r0]; d.nb = hp.rowptr[r1] - d.b0;
+    d.elem_off = (int)eo; d.nelem = nel[p];
+    d.pair_off = (int)po; d.npair = (hp.incptr[r1] - hp.incptr[r0]) * (npe - 1);
+    d.node_off = (int)no; d.nnode = nnd[p];
+    eo += (size_t)d.nelem; po += (size_t)d.npair; no += (size_t)d.nnode;
+    if (d.nelem > FEA_QUAD_ELEMS || d.nb > FEA_QUAD_BLOCKS || d.nnode > FEA_QUAD_NODES || r1 - r0 > FEA_CHUNK_ROWS ||
+        po > 0x7FFFFFFFull) { out.desc.clear(); return; }
+  }
+  out.qelem.assign(eo * 3, 0u); out.qpair.resize(po); out.qnode.resize(no);
+  par_for(np, [&](int lo, int hi) {
+    std::vector<int> el, nd;
+    for (int p = lo; p < hi; ++p) {
+      const QuadDesc &d = out.desc[p];
+      el.clear(); nd.clear();
+      for (int q = hp.incptr[d.r0]; q < hp.incptr[d.r1]; ++q) el.push_back((int)(hp.inc_rows[q] & 0x0FFFFFFFu));
+      std::sort(el.begin(), el.end());
+      el.erase(std::unique(el.begin(), el.end()), el.end());
+      for (int e : el) for (int k = 0; k < npe; ++k) nd.push_back(conn[(size_t)e * npe + k]);
+      std::sort(nd.begin(), nd.end());
+      nd.erase(std::unique(nd.begin(), nd.end()), nd.end());
+      std::copy(nd.begin(), nd.end(), out.qnode.begin() + d.node_off);
+      for (int i = 0; i < d.nelem; ++i) {
+        uint8_t b[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < npe; ++k)
+          b[k] = (uint8_t)(std::lower_bound(nd.begin(), nd.end(), conn[(size_t)el[i] * npe + k]) - nd.begin());
+        const int n0 = conn[(size_t)el[i] * npe];
+        b[10] = (n0 >= d.r0 && n0 < d.r1) ? 1 : 0;
+        uint32_t *w = out.qelem.data() + ((size_t)d.elem_off + i) * 3;
+        for (int k = 0; k < 12; ++k) w[k / 4] |= (uint32_t)b[k] << (8 * (k % 4));
+      }
+      // pairs, visit-major: the npe-1 lanes of a visit read the same state entry (LDS broadcast)
+      size_t w = (size_t)d.pair_off;
+      for (int r = d.r0; r < d.r1; ++r) {
+        const int *cb = hp.colidx.data() + hp.rowptr[r], *ce = hp.colidx.data() + hp.rowptr[r + 1];
+        const uint32_t rowpos = (uint32_t)(hp.rowptr[r] - d.b0);
+        for (int q = hp.incptr[r]; q < hp.incptr[r + 1]; ++q) {
+          const int e = (int)(hp.inc_rows[q] & 0x0FFFFFFFu), la = (int)(hp.inc_rows[q] >> 28);
+          const uint32_t eli = (uint32_t)(std::lower_bound(el.begin(), el.end(), e) - el.begin());
+          bool first = true;
+          for (int lb = 0; lb < npe; ++lb) {
+            if (lb == la) continue;
+            const uint32_t slot = (uint32_t)(std::lower_bound(cb, ce, conn[(size_t)e * npe + lb]) - cb);
+            out.qpair[w++] = eli | ((uint32_t)la << 6) | ((uint32_t)lb << 10) | ((rowpos + slot) << 14) |
+                             ((uint32_t)(r - d.r0) << 22) | (first ? (1u << 26) : 0u);
+            first = false;
+          }
+        }
+      }
+    }
+  });
+  out.ok = true;
+}

@@ -155,6 +155,57 @@ int build_host_pattern(int N, int E, int npe, const int *conn, HostPattern &hp,
     }
     hp.super_achunk.push_back((int)hp.achunk.size());
     hp.achunk.push_back(N);
+  } else if (npe <= 16) {
+    // Assembly partition of the shared-state kernel (kernels_quad.hip): rows
+    // while the K tile, the (row, element, column) pairs and the distinct
+    // elements of the chunk fit one wave's registers and LDS.
+    std::vector<int> stamp((size_t)E, -1), nstamp((size_t)N, -1);
+    int serial = 0;
+    bool ok = true;
+    for (int s0 = 0; s0 < nchunks && ok; s0 += FEA_SUPER_CHUNKS) {
+      const int s1 = std::min(nchunks, s0 + FEA_SUPER_CHUNKS);
+      hp.super_achunk.push_back((int)hp.achunk.size());
+      const int ra = hp.chunk[s0], rb = hp.chunk[s1];
+      int r0 = ra;
+      while (r0 < rb) {
+        int r = r0, nblk = 0, npair = 0, nel = 0, nnod = 0;
+        ++serial;
+        for (; r < rb && r - r0 < FEA_CHUNK_ROWS; ++r) {
+          const int len = hp.rowptr[r + 1] - hp.rowptr[r], vis = hp.incptr[r + 1] - hp.incptr[r];
+          std::vector<int> fresh, nfresh;
+          for (int q = hp.incptr[r]; q < hp.incptr[r + 1]; ++q) {
+            const int e = (int)(hp.inc_rows[q] & 0x0FFFFFFFu);
+            if (stamp[e] != serial) {
+              stamp[e] = serial; fresh.push_back(e);
+              for (int k = 0; k < npe; ++k) {
+                const int g = conn[(size_t)e * npe + k];
+                if (nstamp[g] != serial) { nstamp[g] = serial; nfresh.push_back(g); }
+              }
+            }
+          }
+          // more pairs than one round of the kernel holds only when a single row has them
+          const bool over = nblk + len > FEA_QUAD_BLOCKS || nel + (int)fresh.size() > FEA_QUAD_ELEMS ||
+                            nnod + (int)nfresh.size() > FEA_QUAD_NODES ||
+                            (r > r0 && npair + vis * (npe - 1) > FEA_QUAD_PAIRS);
+          if (over) {
+            if (r == r0) ok = false;               // a single row does not fit: no shared-state assembly for this mesh
+            for (int e : fresh) stamp[e] = -1;     // not taken
+            for (int g : nfresh) nstamp[g] = -1;
+            break;
+          }
+          nblk += len; npair += vis * (npe - 1); nel += (int)fresh.size(); nnod += (int)nfresh.size();
+        }
+        if (!ok) break;
+        hp.achunk.push_back(r0);
+        r0 = r;
+      }
+    }
+    if (ok) {
+      hp.super_achunk.push_back((int)hp.achunk.size());
+      hp.achunk.push_back(N);
+    } else {
+      hp.achunk.clear(); hp.super_achunk.clear();
+    }
   }
 
   // Inside a chunk the (row, element) visits are dealt round-robin over the

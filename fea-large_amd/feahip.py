@@ -17,7 +17,7 @@ HOST_LIB_PATH = os.path.join(_HERE, "libfeahost.so")
 
 MODEL_A5, MODEL_COMPRESSIBLE_NEOHOOKEAN = 0, 1
 CG, PCG_ILU, CHOLESKY = 0, 1, 2
-ASM_AUTO, ASM_ROWOWNER, ASM_ATOMIC, ASM_PATCH, ASM_STAGED, ASM_PAIRED, ASM_PIPELINED = 0, 1, 2, 3, 4, 5, 6
+ASM_AUTO, ASM_ROWOWNER, ASM_ATOMIC, ASM_PATCH, ASM_STAGED, ASM_PAIRED, ASM_PIPELINED, ASM_SHARED = 0, 1, 2, 3, 4, 5, 6, 7
 TETRAHEDRA10, TETRAHEDRA4 = 0, 1
 
 _dp = C.POINTER(C.c_double)

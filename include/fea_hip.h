@@ -55,11 +55,15 @@ enum {
                               shared blocks summed in registers (fewer LDS
                               operations; measured 5 % slower than STAGED
                               for K+f, 8 % faster for f alone)               */
-  FEAHIP_ASM_PIPELINED = 6 /* STAGED, one wave walking a run of chunks with
+  FEAHIP_ASM_PIPELINED = 6,/* STAGED, one wave walking a run of chunks with
                               the next chunk's loads (LDS-DMA) in flight
                               under the current one; hides the load latency
                               but the LDS adds bound both: equal to STAGED
                               within 2 %                         */
+  FEAHIP_ASM_SHARED = 7    /* 10-node tets: Gauss-point states evaluated once
+                              per chunk element and shared through LDS, the
+                              blocks of a (row, element, column) pair summed
+                              over the Gauss points in registers              */
 };
 
 /* ---- lifetime ----------------------------------------------------------- */

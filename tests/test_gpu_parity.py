@@ -38,6 +38,8 @@ def make_pair(deck, x=None):
 def check_assembly(s, o, strategies=(feahip.ASM_ROWOWNER, feahip.ASM_ATOMIC)):
     if s.npe == 4 and s.G == 1:
         strategies = tuple(strategies) + (feahip.ASM_PATCH, feahip.ASM_STAGED, feahip.ASM_PAIRED, feahip.ASM_PIPELINED)
+    if s.npe == 10:
+        strategies = tuple(strategies) + (feahip.ASM_SHARED,)
     o.update_state()
     o.create_stiffness()
     o.create_residual_forces()
@@ -365,7 +367,10 @@ def test_error_paths():
     with pytest.raises(feahip.FeaHipError, match="solver type"):
         s.solve_slae(9, 1e-10, 10)
     with pytest.raises(feahip.FeaHipError, match="strategy"):
-        s.set_assembly(7)
+        s.set_assembly(8)
+    s.set_assembly(feahip.ASM_SHARED)                   # a 10-node strategy on linear tets: refused at the launch
+    with pytest.raises(feahip.FeaHipError, match="10-node"):
+        s.create_stiffness()
     s.close()
     bad = mesh.bar_deck(dims=(1, 1, 1))
     bad.elements = bad.elements.copy()
