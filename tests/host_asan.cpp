@@ -1,0 +1,45 @@
+// host-only sanitizer run over the map builders (pattern, visits, pairs, patches, quad, multigrid setup)
+#include "feahip_internal.h"
+#include "amg.h"
+#include <cstdio>
+static const int P[6][3] = {{0,1,2},{0,2,1},{1,0,2},{1,2,0},{2,0,1},{2,1,0}};
+int main()
+{
+  for (int quad = 0; quad < 2; ++quad) {
+    const int nx = quad ? 9 : 24, ny = quad ? 20 : 60, nz = quad ? 8 : 22, m = quad ? 2 : 1;
+    const int gx = m * nx + 1, gy = m * ny + 1, gz = m * nz + 1;
+    auto id = [&](int i, int j, int k) { return (j * gz + k) * gx + i; };
+    std::vector<int> conn; std::vector<double> pos((size_t)gx * gy * gz * 3);
+    for (int j = 0; j < gy; ++j) for (int k = 0; k < gz; ++k) for (int i = 0; i < gx; ++i) {
+      double *p = &pos[(size_t)id(i, j, k) * 3]; p[0] = i; p[1] = j; p[2] = k; }
+    static const int ED[6][2] = {{0,1},{1,2},{0,2},{0,3},{1,3},{2,3}};
+    for (int j = 0; j < ny; ++j) for (int k = 0; k < nz; ++k) for (int i = 0; i < nx; ++i)
+      for (int p = 0; p < 6; ++p) {
+        int c[3] = {i * m, j * m, k * m}; int v[4][3];
+        for (int d = 0; d < 3; ++d) v[0][d] = c[d];
+        for (int s = 0; s < 3; ++s) { c[P[p][s]] += m; for (int d = 0; d < 3; ++d) v[s + 1][d] = c[d]; }
+        for (int s = 0; s < 4; ++s) conn.push_back(id(v[s][0], v[s][1], v[s][2]));
+        if (quad) for (auto &e : ED) conn.push_back(id((v[e[0]][0] + v[e[1]][0]) / 2, (v[e[0]][1] + v[e[1]][1]) / 2, (v[e[0]][2] + v[e[1]][2]) / 2));
+      }
+    const int npe = quad ? 10 : 4, N = gx * gy * gz, E = (int)conn.size() / npe;
+    HostPattern hp; std::string err;
+    if (build_host_pattern(N, E, npe, conn.data(), hp, err)) { printf("pattern: %s\n", err.c_str()); return 1; }
+    if (!quad) {
+      HostPatches pt; build_host_patches(N, E, conn.data(), hp, pt);
+      HostVisits hv; build_host_visits(N, E, conn.data(), hp, hv);
+      HostPairs pr; build_host_pairs(conn.data(), hp, hv, pr);
+      printf("tet4: N=%d E=%d chunks=%zu achunks=%zu patches=%d visits=%d pairs=%d\n", N, E, hp.chunk.size() - 1, hp.achunk.size() - 1, (int)pt.ok, (int)hv.ok, (int)pr.ok);
+    } else {
+      HostQuad hq; build_host_quad(N, E, npe, conn.data(), hp, hq);
+      printf("tet10: N=%d E=%d chunks=%zu achunks=%zu quad=%d pairs=%zu\n", N, E, hp.chunk.size() - 1, hp.achunk.size() - 1, (int)hq.ok, hq.qpair.size());
+    }
+    std::vector<HostAmgLevel> lv;
+    const bool ok = build_host_amg(hp.rowptr, hp.colidx, pos, lv);
+    printf("  amg: ok=%d levels=%zu", (int)ok, lv.size());
+    for (auto &L : lv) printf(" [N=%d S=%d Sc=%d nnzb=%zu]", L.N, L.S, L.Sc, L.colidx.size());
+    printf("\n");
+    ShardPlan sp;
+    (void)sp;
+  }
+  return 0;
+}

@@ -214,3 +214,25 @@ def test_gmsh_export_format(tmp_path):
     buf = C.create_string_buffer(64)
     feahip.load_host_library().fea_export_name(b"dir.d/neohook_brick.sexp", buf)
     assert buf.value == b"dir.d/neohook_brick.msh"
+
+
+def test_host_map_builders_under_sanitizers(tmp_path):
+    """pattern / visit / pair / patch / shared-state / multigrid-setup builders
+    (host C++, index arithmetic over the mesh) compiled with AddressSanitizer
+    and UBSan and run on a TET4 and a TET10 block: no report, all maps built."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("needs g++ and the HIP headers")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "fea-large_amd", "csrc")
+    exe = str(tmp_path / "host_asan")
+    cmd = ["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17",
+           "-I" + src, "-I" + os.path.join(root, "include"), "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-o", exe,
+           os.path.join(root, "tests", "host_asan.cpp")] + [os.path.join(src, f) for f in
+                                                            ("pattern.cpp", "patches.cpp", "amg_setup.cpp")] + ["-lpthread"]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ERROR" not in r.stderr and "runtime error" not in r.stderr
+    assert "patches=1 visits=1 pairs=1" in r.stdout and "quad=1" in r.stdout and r.stdout.count("amg: ok=1") == 2
