@@ -128,11 +128,39 @@ int dist_newton(std::vector<feahip_ctx *> &R, int load_increments, int max_newto
         EACH(feahip_create_stiffness_and_residual(c));                // :185 + :200
       }
       EACH(feahip_apply_prescribed_bc(c, 0.0));                       // :203
-      if ((rc = dist_solve_pcg(R, solver_type, solver_tolerance, solver_max_iter, nullptr, nullptr))) return rc;  // :205
+      if (R.size() == 1) {                                            // :205 (single rank: the context's preconditioner choice applies)
+        if ((rc = feahip_solve_slae(R[0], solver_type, solver_tolerance, solver_max_iter, nullptr, nullptr))) return rc;
+      } else if ((rc = dist_solve_pcg(R, solver_type, solver_tolerance, solver_max_iter, nullptr, nullptr))) return rc;
       if ((rc = dist_energy(R, &tolerance))) return rc;               // :208-210, identical on every rank
       if (tol_log && nlog < tol_log_cap) tol_log[nlog] = tolerance;
       nlog++;
-      if ((rc = dist_update_nodes_with_solution(R, nullptr))) return rc;   // :216
+      const int ls_max = R[0]->linesearch_max;
+      if (ls_max <= 0) {
+        if ((rc = dist_update_nodes_with_solution(R, nullptr))) return rc;   // :216
+      } else {
+        // Golden-section search for the step length eta in [1/2, 1] that minimises |eta <u, R(x + eta u)>|
+        // (solver-prototype/cartesian3d/large/cartesian3d_large.m:85-119; the C solver parses
+        // line-search :max and never uses it, fea_solver.c:1517).  Two residual assemblies per iteration.
+        const double tau = (sqrt(5.0) - 1.0) / 2.0;
+        double a = 0.5, b = 1.0, eta = 1.0, at = 0.0;                 // at: the multiple of u currently added to x
+        for (int ls = 0; ls < ls_max; ++ls) {
+          const double x1 = b - tau * (b - a), x2 = a + tau * (b - a);
+          double f[2];
+          for (int k = 0; k < 2; ++k) {
+            const double xk = k == 0 ? x1 : x2;
+            if ((rc = dist_nodes_add_scaled(R, xk - at, at == 0.0))) return rc;
+            at = xk;
+            EACH(feahip_create_residual_forces(c));
+            double uf = 0;
+            if ((rc = dist_energy(R, &uf))) return rc;                // <u, -R> with the sign of the residual vector f
+            f[k] = fabs(xk * uf);
+          }
+          if (f[0] > f[1]) a = x1; else b = x2;
+          if (fabs(tolerance) < f[0] && fabs(tolerance) < f[1]) { eta = 1.0; break; }
+          eta = 0.5 * (x1 + x2);
+        }
+        if ((rc = dist_nodes_add_scaled(R, eta - at, at == 0.0))) return rc;
+      }
       EACH(feahip_update_state(c, nullptr));                          // :217-218
     } while (fabs(tolerance) > desired_tolerance && it < max_newton); // :220-221
     if (its_log) its_log[step] = it;

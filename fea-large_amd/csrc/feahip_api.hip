@@ -251,6 +251,14 @@ extern "C" int feahip_set_preconditioner(feahip_ctx *c, int kind)
   return FEAHIP_OK;
 }
 
+extern "C" int feahip_set_line_search(feahip_ctx *c, int max_iterations)
+{
+  CTX_GUARD(c);
+  if (max_iterations < 0) { c->err = "line search iterations must be >= 0"; return FEAHIP_EINVAL; }
+  c->linesearch_max = max_iterations;
+  return FEAHIP_OK;
+}
+
 extern "C" int feahip_set_row_shard(feahip_ctx *c, int rank, int nranks)
 {
   CTX_GUARD(c);

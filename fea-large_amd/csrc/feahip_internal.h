@@ -115,6 +115,8 @@ struct feahip_ctx {
   int last_bad = 0;
 
   // preconditioner of PCG_ILU / CHOLESKY solves: 0 = 3x3 block-Jacobi, 1 = aggregation multigrid (amg.h)
+  // golden-section line search along the Newton step: iterations (0 = off, the reference's solve())
+  int linesearch_max = 0;
   int precond = 0;
   void *amg = nullptr;         // AmgHierarchy, built on first use
 };
@@ -225,6 +227,7 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF);
 int launch_state_export(feahip_ctx *c);
 int launch_apply_bc(feahip_ctx *c, double lambda);
 int launch_update_nodes_bc(feahip_ctx *c, double lambda);
+int dist_nodes_add_scaled(std::vector<feahip_ctx *> &R, double eta, bool exchange);
 int launch_update_nodes_solution(feahip_ctx *c, const double *d_u);
 int launch_spmv(feahip_ctx *c, const double *d_xv, double *d_yv);
 int solve_pcg(feahip_ctx *c, int type, double tol, int max_iter, int *iters,

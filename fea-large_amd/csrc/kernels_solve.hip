@@ -673,6 +673,28 @@ int dist_update_nodes_with_solution(std::vector<feahip_ctx *> &R, const double *
   return FEAHIP_OK;
 }
 
+// x += eta u on every rank (line search: trial configurations along the Newton step).
+// `exchange`: the owners' u travels to the halo copies first (once per step is enough).
+__global__ void k_nodes_axpy(int ndof, double eta, const double *u, double *x)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ndof) return;
+  x[(size_t)(t / 3) * 4 + t % 3] += eta * u[t];
+}
+
+int dist_nodes_add_scaled(std::vector<feahip_ctx *> &R, double eta, bool exchange)
+{
+  Transport *T = R[0]->tr;
+  int rc;
+  FOR_RANKS(c) c->state_valid = false;
+  if (T && exchange && (rc = T->exchange(R, 1))) return rc;
+  FOR_RANKS(c) {
+    hipLaunchKernelGGL(k_nodes_axpy, dim3((c->ndof + 255) / 256), dim3(256), 0, c->stream, c->ndof, eta, c->d_u, c->d_x);
+    FEA_HIP_CHECK(c, hipGetLastError());
+  }
+  return FEAHIP_OK;
+}
+
 int time_pcg_iteration(feahip_ctx *c, int warmup, int iters, double *avg_ms)
 {
   std::vector<feahip_ctx *> R(1, c);

@@ -55,6 +55,7 @@ ABI = {
     "feahip_spmv": [C.c_void_p, _dp, _dp],
     "feahip_set_assembly": [C.c_void_p, C.c_int],
     "feahip_set_preconditioner": [C.c_void_p, C.c_int],
+    "feahip_set_line_search": [C.c_void_p, C.c_int],
     "feahip_set_row_shard": [C.c_void_p, C.c_int, C.c_int],
     "feahip_comm_unique_id": [C.c_void_p, C.c_int],
     "feahip_comm_init": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
@@ -336,8 +337,10 @@ class FeaSolver:
             self._chk(self._lib.feahip_update_nodes_with_solution(self._ctx, _d(u)))
 
     def solve(self, load_increments=None, max_newton=None, modified_newton=None, desired_tolerance=None,
-              solver_type=None, solver_tolerance=None, solver_max_iter=None):
+              solver_type=None, solver_tolerance=None, solver_max_iter=None, line_search=None):
         d = self.deck
+        if line_search is not None:
+            self.set_line_search(line_search)
         li = d.load_increments_count if load_increments is None else load_increments
         mn = d.max_newton_count if max_newton is None else max_newton
         cap = li * mn
@@ -408,6 +411,9 @@ class FeaSolver:
     # ---- tuning / measurement ------------------------------------------
     def set_preconditioner(self, kind):
         self._chk(self._lib.feahip_set_preconditioner(self._ctx, kind))
+
+    def set_line_search(self, max_iterations):
+        self._chk(self._lib.feahip_set_line_search(self._ctx, max_iterations))
 
     def set_assembly(self, strategy):
         self._chk(self._lib.feahip_set_assembly(self._ctx, strategy))

@@ -213,6 +213,14 @@ int feahip_set_assembly(feahip_ctx *ctx, int strategy);
  * context keeps block-Jacobi).  Either way the solve runs to the requested
  * residual, so the solution is the same to that tolerance.                   */
 int feahip_set_preconditioner(feahip_ctx *ctx, int kind);
+/* Line search along every Newton step of feahip_solve / feahip_group_solve:
+ * golden-section search, `max_iterations` iterations, for the step length in
+ * [1/2, 1] that minimises |eta <u, R(x + eta u)>| -- what the reference's
+ * prototype does (solver-prototype/cartesian3d/large/cartesian3d_large.m:
+ * 85-119) and what its C solver parses as `line-search :max` and leaves unused
+ * (fea_solver.c:1517, sexp_loader.c:153-159).  0 (default) = the reference's
+ * solve().  Two residual assemblies per iteration.                         */
+int feahip_set_line_search(feahip_ctx *ctx, int max_iterations);
 /* Restricts assembly and SpMV to this rank's slab of block rows (rank of
  * nranks, contiguous row ranges of near-equal block count).  Rows are owned
  * by exactly one rank; a rank visits every element that touches its rows, so

@@ -293,6 +293,57 @@ def test_lame_cylinder_a5(quadratic):
     s.close(); o.close()
 
 
+def test_line_search_matches_the_prototype_restated_on_the_oracle():
+    """feahip_set_line_search: golden-section search of the step length in
+    [1/2, 1] for min |eta <u, R(x + eta u)>| (cartesian3d_large.m:85-119; the C
+    solver parses `line-search :max` and leaves it unused).  The same loop
+    restated with the oracle's primitives gives the same iteration count,
+    the same <u,f> sequence and the same displacements."""
+    LS = 5
+    deck = mesh.bar_deck(dims=(3, 9, 3), dy=0.3, load_increments_count=1, max_newton_count=25,
+                         desired_tolerance=1e-16, modified_newton=False)
+    s = feahip.FeaSolver(deck)
+    done, its, tol = s.solve(solver_type=feahip.CHOLESKY, line_search=LS)
+    o = OracleSolver(deck)
+    o.update_nodes_with_bc(1.0); o.update_state(); o.create_stiffness()
+    tau, olog, it = (np.sqrt(5.0) - 1.0) / 2.0, [], 0
+    while True:
+        it += 1
+        if it > 1:
+            o.create_stiffness()
+        o.create_residual_forces(); o.apply_prescribed_bc(0.0); o.solve_slae(feahip.CHOLESKY)
+        t = o.energy(); olog.append(t)
+        base, u = o.nodes().copy(), o.solution().copy()
+        a, b, eta = 0.5, 1.0, 1.0
+        for _ in range(LS):
+            x1, x2 = b - tau * (b - a), a + tau * (b - a)
+            f = []
+            for xk in (x1, x2):
+                o.set_nodes(base + xk * u.reshape(-1, 3)); o.update_state(); o.create_residual_forces()
+                f.append(abs(xk * float(o.forces() @ u)))
+            if f[0] > f[1]:
+                a = x1
+            else:
+                b = x2
+            if abs(t) < f[0] and abs(t) < f[1]:
+                eta = 1.0
+                break
+            eta = 0.5 * (x1 + x2)
+        o.set_nodes(base + eta * u.reshape(-1, 3)); o.update_state()
+        if not (abs(t) > deck.desired_tolerance and it < deck.max_newton_count):
+            break
+    assert done == 1 and its[0] == it
+    assert np.abs(tol - np.array(olog)).max() < 1e-9 * np.abs(olog).max()
+    assert rel(s.nodes() - deck.nodes, o.nodes() - deck.nodes) < U_TOL
+    # and it is a different path from the plain Newton loop on this step
+    p = feahip.FeaSolver(deck)
+    pd, pits, ptol = p.solve(solver_type=feahip.CHOLESKY)
+    assert pd != 1 or pits[0] != its[0] or np.abs(ptol[1] - tol[1]) > 1e-6 * abs(tol[1])
+    with pytest.raises(feahip.FeaHipError):
+        p.set_line_search(-1)
+    s.close(); p.close(); o.close()
+
+
 def test_full_newton_tet4_patch_test_closed_form():
     """Rotation-free uniaxial recipe on linear tets: the Neo-Hookean closed
     form of exact-solutions/uniaxial/uniaxial_neohookean_bonet.m is the exact
