@@ -46,7 +46,7 @@ def test_1m_stiffness_properties(block_1m):
     # the three strategies agree at this size too
     f0 = s.forces()
     ya = s.spmv(a)
-    for strat in (feahip.ASM_ROWOWNER, feahip.ASM_PATCH, feahip.ASM_STAGED):
+    for strat in (feahip.ASM_ROWOWNER, feahip.ASM_PATCH, feahip.ASM_STAGED, feahip.ASM_PIPELINED):
         s.set_assembly(strat)
         s.create_stiffness_and_residual()
         assert np.abs(s.spmv(a) - ya).max() < 1e-12 * np.abs(ya).max()
@@ -71,6 +71,51 @@ def test_1m_uniaxial_patch_test_closed_form():
     assert np.abs(s.nodes() - expect).max() < 2e-11
     S = s.stresses()
     assert np.abs(S[:, 0, 1, 1] - syy).max() < 1e-8
+    s.close()
+
+
+def test_1m_multigrid_newton_step_equals_block_jacobi(block_1m):
+    """One Newton step of the clamped 1M-tet block solved with both
+    preconditioners: same <u,f>, same displacements to 1e-10, and the
+    multigrid PCG needs less than a sixth of the iterations."""
+    deck, s = block_1m
+    out = []
+    for kind in (0, 1):
+        s.set_preconditioner(kind)
+        s.set_nodes(deck.nodes)
+        s.update_nodes_with_bc(1.0)
+        s.create_stiffness_and_residual()
+        s.apply_prescribed_bc(0.0)
+        it, res = s.solve_slae(feahip.PCG_ILU, 1e-14, 40000)
+        assert res < 1e-13
+        out.append((it, s.energy(), s.solution()))
+    s.set_preconditioner(0)
+    (it0, e0, u0), (it1, e1, u1) = out
+    assert it1 * 6 < it0
+    assert abs(e1 - e0) < 1e-10 * abs(e0)
+    assert np.abs(u1 - u0).max() < 1e-10 * np.abs(u0).max()
+
+
+def test_500k_tet10_shared_state_assembly_properties():
+    """configs[4] element (10-node, here 5 points): the shared-state kernel
+    on 497 664 elements agrees with the generic row-owner kernel, and K is
+    symmetric and translation-free."""
+    deck = mesh.bar_deck(n=24, quadratic=True)
+    s = feahip.FeaSolver(deck)
+    s.set_nodes(mesh.deformed_state(deck.nodes))
+    s.create_stiffness_and_residual()                    # AUTO = shared-state kernel
+    assert s.update_state() == 0
+    rng = np.random.default_rng(11)
+    a, b = rng.normal(size=s.ndof), rng.normal(size=s.ndof)
+    ya, f0 = s.spmv(a), s.forces()
+    t = np.zeros(s.ndof); t[2::3] = 1.0
+    assert np.abs(s.spmv(t)).max() < 1e-11 * np.abs(ya).max()
+    assert abs(b @ ya - a @ s.spmv(b)) < 1e-11 * abs(b @ ya)
+    s.set_assembly(feahip.ASM_ROWOWNER)
+    s.create_stiffness_and_residual()
+    assert np.abs(s.spmv(a) - ya).max() < 1e-12 * np.abs(ya).max()
+    # f is a sum of element contributions ~100x its own size here (near equilibrium): 1e-11 of max|f|
+    assert np.abs(s.forces() - f0).max() < 1e-11 * np.abs(f0).max()
     s.close()
 
 
