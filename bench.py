@@ -118,19 +118,9 @@ def main():
     solver = feahip.FeaSolver(deck, device=local)
     comm_ok = False
     if world > 1:
-        # RCCL communicator for the sharded linear solve (halo rows + scalar all-reduces).  The timed
-        # assembly below needs no collective; if the communicator cannot be built it still runs.
-        uid = [feahip.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        try:
-            solver.comm_init(rank, world, uid[0])
-            comm_ok = True
-        except Exception as e:                      # noqa: BLE001
-            print(f"[rank {rank}] RCCL communicator unavailable ({e}); assembly-only sharding", file=sys.stderr)
-            solver.set_row_shard(rank, world)
-        flags = [None] * world
-        dist.all_gather_object(flags, comm_ok)
-        comm_ok = all(flags)
+        # the timed assembly needs the row shard only (no collective); the RCCL communicator of the
+        # sharded solve is built afterwards, under the watchdog, so a wedged rendezvous cannot cost the line
+        solver.set_row_shard(rank, world)
     solver.set_nodes(mesh.deformed_state(deck.nodes))
     sz = solver.sizes()
     t_setup = time.perf_counter() - t_setup
@@ -199,8 +189,22 @@ def main():
 
     watchdog = threading.Timer(240.0, bail)
     watchdog.daemon = True
+    watchdog.start()
+    if world > 1:
+        # RCCL communicator for the sharded linear solve (halo rows + scalar all-reduces)
+        try:
+            uid = [feahip.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            solver.comm_init(rank, world, uid[0])
+            comm_ok = True
+        except Exception as e:                      # noqa: BLE001
+            print(f"[rank {rank}] RCCL communicator unavailable ({e}); assembly-only sharding", file=sys.stderr)
+            solver.set_row_shard(rank, world)
+        flags = [None] * world
+        dist.all_gather_object(flags, comm_ok)
+        comm_ok = all(flags)
+        extras["rccl_sharded_solve"] = comm_ok
     if world == 1 or comm_ok:
-        watchdog.start()
         try:
             extras["pcg_iteration_ms"] = solver.time_kernel(4, warmup=2, iters=10)      # collective when sharded
             if not args.no_newton:
@@ -238,7 +242,7 @@ def main():
                     solver.set_preconditioner(0)
         except Exception as e:                      # noqa: BLE001
             extras["solve_leg"] = f"failed: {e}"
-        watchdog.cancel()
+    watchdog.cancel()
     if rank == 0 and args.cpu_sample > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
     emit()
