@@ -410,6 +410,42 @@ def test_brick_fine_one_assembly(decks_dir, tmp_path):
     s.close()
 
 
+def test_isolated_node_and_single_element_edge_cases():
+    """Ragged inputs.  A node no element refers to: its row is just its
+    diagonal block; pinned, it must not disturb anything -- the run equals
+    the run without it (which the oracle checks), bit for bit in the
+    iteration counts.  (The reference has no such deck: its sparse matrix has
+    no entry to put the 1 of a prescribed dof on.)  And a mesh of one element."""
+    base = mesh.bar_deck(dims=(2, 3, 2), load_increments_count=1, max_newton_count=20, desired_tolerance=1e-18)
+    s0, o, (sd, sits, stol), (od, oits, otol) = run_newton_both(base, 1, True)
+    assert sd == od == 1 and list(sits[:1]) == list(oits[:1])
+    deck = mesh.bar_deck(dims=(2, 3, 2), load_increments_count=1, max_newton_count=20, desired_tolerance=1e-18)
+    N = len(deck.nodes)
+    deck.nodes = np.vstack([deck.nodes, [[5.0, 5.0, 5.0]]])
+    deck.presc_node = np.append(deck.presc_node, N).astype(np.int32)
+    deck.presc_type = np.append(deck.presc_type, 7).astype(np.int32)
+    deck.presc_values = np.vstack([deck.presc_values, [[0.0, 0.0, 0.0]]])
+    s = feahip.FeaSolver(deck)
+    d1, its1, tol1 = s.solve(solver_type=feahip.CHOLESKY, load_increments=1, modified_newton=True)
+    assert d1 == 1 and its1[0] == sits[0]
+    assert rel(s.nodes()[:N] - base.nodes, o.nodes() - base.nodes) < U_TOL
+    assert np.array_equal(s.nodes()[N], deck.nodes[N])
+    off, idx, val = s.matrix_yale()
+    assert off[-1] == o.offsets()[-1] + 9 and np.all(np.isfinite(val))     # one more 3x3 block: the diagonal of the lone node
+    s.close(); s0.close(); o.close()
+    one = mesh.bar_deck(dims=(1, 1, 1))
+    keep = np.unique(one.elements[0])
+    remap = -np.ones(len(one.nodes), dtype=np.int64); remap[keep] = np.arange(4)
+    one.nodes = one.nodes[keep]
+    one.elements = remap[one.elements[:1]].astype(np.int32)     # one tetrahedron
+    sel = np.isin(one.presc_node, keep)
+    one.presc_node = remap[one.presc_node[sel]].astype(np.int32)
+    one.presc_type, one.presc_values = one.presc_type[sel], one.presc_values[sel]
+    s, o = make_pair(one, mesh.deformed_state(one.nodes))
+    check_assembly(s, o)
+    s.close(); o.close()
+
+
 def test_error_paths():
     deck = mesh.bar_deck(dims=(1, 1, 1))
     s = feahip.FeaSolver(deck)
