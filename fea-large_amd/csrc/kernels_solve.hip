@@ -342,10 +342,14 @@ void k_cg_init_scalars(int nparts, const double *part, const double *gred, doubl
   }
 }
 
-// alpha = r.z / p.q ; x += alpha p ; r -= alpha q ; partial sums of r.Mr, r.r
+// alpha = r.z / p.q ; x += alpha p ; r -= alpha q ; partial sums of r.Mr, r.r.
+// zq (may alias q, which is dead once read): z = M r is left there for
+// k_cg_direction, which then reads one vector instead of r and the 72-byte
+// inverse blocks again.
 __global__ __launch_bounds__(256)
 void k_cg_update(int a0, int a1, int it, int n_pq, const double *p, const double *q, const double *minv,
-                 double *x, double *r, double *part, const double *gred, const double *scal, const int *flag)
+                 double *x, double *r, double *part, const double *gred, const double *scal, const int *flag,
+                 double *zq)
 {
   __shared__ double scratch[5];
   if (flag[0] != 0) return;
@@ -365,6 +369,7 @@ void k_cg_update(int a0, int a1, int it, int n_pq, const double *p, const double
     for (int i = 0; i < 3; ++i) {
       const double z = minv ? m[3 * i] * rv[0] + m[3 * i + 1] * rv[1] + m[3 * i + 2] * rv[2] : rv[i];
       srz += rv[i] * z; srr += rv[i] * rv[i];
+      if (zq) zq[(size_t)a * 3 + i] = z;
     }
   }
   srz = block_sum(srz, scratch); srr = block_sum(srr, scratch);
@@ -549,14 +554,15 @@ static int enq_cg_iteration(std::vector<feahip_ctx *> &R, Transport *T, int it)
     const int gv = vgrid(c);
     hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(256), 0, c->stream, own0(c), own1(c), it, spmv_grid(c), c->d_p,
                        c->d_q, c->d_minv, c->d_u, c->d_r, c->d_part, T ? c->d_scal + 8 : (const double *)nullptr,
-                       c->d_scal, c->d_flag);
+                       c->d_scal, c->d_flag, c->d_q);
     if (T) hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, gv, 2, RB, c->d_part + RB, c->d_scal + 9);
   }
   if (T && (rc = T->allreduce(R, 1, 2))) return rc;              // r.z, r.r
   FOR_RANKS(c) {
     const int gv = vgrid(c);
-    hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(256), 0, c->stream, own0(c), own1(c), it, gv, c->d_r, c->d_minv,
-                       c->d_p, c->d_part, T ? c->d_scal + 9 : (const double *)nullptr, c->d_scal, c->d_flag);
+    hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(256), 0, c->stream, own0(c), own1(c), it, gv, c->d_q,
+                       (const double *)nullptr, c->d_p, c->d_part, T ? c->d_scal + 9 : (const double *)nullptr, c->d_scal,
+                       c->d_flag);                                  // z = M r is in q since k_cg_update
   }
   return FEAHIP_OK;
 }
@@ -732,7 +738,8 @@ void enq_spmv_arrays(hipStream_t stream, int nchunks, const int *chunk, const in
 void enq_cg_update_plain(feahip_ctx *c, int it)
 {
   hipLaunchKernelGGL(k_cg_update, dim3(vgrid(c)), dim3(256), 0, c->stream, own0(c), own1(c), it, spmv_grid(c), c->d_p,
-                     c->d_q, (const double *)nullptr, c->d_u, c->d_r, c->d_part, (const double *)nullptr, c->d_scal, c->d_flag);
+                     c->d_q, (const double *)nullptr, c->d_u, c->d_r, c->d_part, (const double *)nullptr, c->d_scal, c->d_flag,
+                     (double *)nullptr);
 }
 void enq_cg_direction_from(feahip_ctx *c, int it, const double *z)
 {
