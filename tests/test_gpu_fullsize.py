@@ -119,6 +119,60 @@ def test_500k_tet10_shared_state_assembly_properties():
     s.close()
 
 
+def test_1m_lame_cylinder_a5_sharded_equals_unsharded():
+    """configs[3] geometry and model at 1.2M linear tets (40 x 160 x 32 cells of
+    the r-theta-z block): K symmetric and translation-free along the axis
+    before BCs, reference state stress-free, and the rows one rank of 8 owns
+    come out bit-identical to the unsharded assembly."""
+    deck = mesh.cylinder_deck(40, 160, 32)
+    assert len(deck.elements) == 40 * 160 * 32 * 6
+    s = feahip.FeaSolver(deck)
+    s.create_residual_forces()
+    assert np.abs(s.forces()).max() < 1e-10
+    s.update_nodes_with_bc(1.0)
+    s.create_stiffness_and_residual()
+    assert s.update_state() == 0
+    rng = np.random.default_rng(13)
+    a, b = rng.normal(size=s.ndof), rng.normal(size=s.ndof)
+    ya = s.spmv(a)
+    t = np.zeros(s.ndof); t[2::3] = 1.0
+    assert np.abs(s.spmv(t)).max() < 1e-11 * np.abs(ya).max()
+    assert abs(b @ ya - a @ s.spmv(b)) < 1e-11 * abs(b @ ya)
+    s.set_row_shard(5, 8)
+    r0, r1 = s.owned_rows()
+    s.create_stiffness_and_residual()
+    assert np.array_equal(s.spmv(a)[3 * r0:3 * r1], ya[3 * r0:3 * r1])
+    s.close()
+
+
+def test_tet10_27_point_rule_at_scale():
+    """configs[4] element and rule (10-node, 27 Gauss points) on 165 888
+    elements: shared-state kernel = generic kernel, K symmetric, and the
+    27-point K equals the 5-point K to the accuracy of the quadrature on this
+    smooth state (both rules integrate the same polynomial tangent exactly
+    to O(h^2) here)."""
+    deck = mesh.bar_deck(dims=(12, 96, 24), quadratic=True, gauss=27)
+    s = feahip.FeaSolver(deck)
+    x = mesh.deformed_state(deck.nodes)
+    s.set_nodes(x)
+    s.create_stiffness_and_residual()
+    assert s.update_state() == 0
+    rng = np.random.default_rng(17)
+    a, b = rng.normal(size=s.ndof), rng.normal(size=s.ndof)
+    ya = s.spmv(a)
+    assert abs(b @ ya - a @ s.spmv(b)) < 1e-11 * abs(b @ ya)
+    s.set_assembly(feahip.ASM_ROWOWNER)
+    s.create_stiffness_and_residual()
+    assert np.abs(s.spmv(a) - ya).max() < 1e-12 * np.abs(ya).max()
+    s.close()
+    d5 = mesh.bar_deck(dims=(12, 96, 24), quadratic=True, gauss=5)
+    s5 = feahip.FeaSolver(d5)
+    s5.set_nodes(x)
+    s5.create_stiffness_and_residual()
+    assert np.abs(s5.spmv(a) - ya).max() < 1e-3 * np.abs(ya).max()
+    s5.close()
+
+
 def test_10m_assembly_properties():
     """configs[2]: the headline mesh.  One assembly, checked by K.t = 0,
     symmetry and f = 0 at the reference state."""
