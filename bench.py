@@ -226,8 +226,9 @@ def main():
                 extras.update({"newton_iters_per_s": 1.0 / tn, "newton_iteration_s": tn, "cg_iterations": its,
                                "cg_relative_residual": res, "energy_u_f": en,
                                "newton_preconditioner": "3x3 block-Jacobi"})
-                if world == 1:
-                    # same iteration with the aggregation-multigrid preconditioner (single rank only);
+                if True:
+                    # same iteration with the aggregation-multigrid preconditioner: sharded, every rank runs the
+                    # W-cycle on its own diagonal block (block-Jacobi over the ranks, no collective inside it)
                     extras["block_jacobi"] = {"newton_iteration_s": tn, "cg_iterations": its}
                     t_amg = time.perf_counter()
                     solver.set_preconditioner(1)          # builds the aggregates and coarse patterns on the host, once

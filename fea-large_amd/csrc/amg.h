@@ -50,6 +50,7 @@ struct AmgHierarchy {
                                          // 10M-tet block, PCG to 1e-14: V-cycle 274 iterations (over 1.5), W-cycle below the
                                          // finest level 150, W-cycle on every level 94 (339 ms against 1 704 ms block-Jacobi)
   bool numeric_valid = false;
+  int row0 = 0, row1 = 0;                // rows of level 0 this hierarchy covers (the rank's own)
   double *d_z = nullptr;                 // level-0 output of the V-cycle
   double *d_pw = nullptr;                // scratch for the power iteration
   long long bytes = 0;
@@ -66,9 +67,11 @@ struct HostAmgLevel {
   std::vector<double> doff;
 };
 bool build_host_amg(const std::vector<int> &rowptr, const std::vector<int> &colidx, const std::vector<double> &pos,
-                    std::vector<HostAmgLevel> &out);
+                    int own0, int own1, std::vector<HostAmgLevel> &out);
 
 // device side (amg.hip)
 int amg_create(feahip_ctx *c);
 void amg_destroy(feahip_ctx *c);
-int solve_pcg_amg(feahip_ctx *c, double tol, int max_iter, int *iters, double *resid);
+int amg_prepare(feahip_ctx *c);                      // hierarchy for the current row range, numeric part for the current K
+double *amg_apply(feahip_ctx *c, const double *r);    // z = M^-1 r on the rank's rows; returns z
+double *amg_result(feahip_ctx *c);                    // the z of the last amg_apply

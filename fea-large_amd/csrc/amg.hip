@@ -4,14 +4,8 @@
 #include <cstdlib>
 
 // from kernels_solve.hip
-void enq_spmv_arrays(hipStream_t stream, int nchunks, const int *chunk, const int *rowptr, const int *colidx,
+void enq_spmv_arrays(hipStream_t stream, int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx,
                      const double *K, const double *xv, double *yv);
-void enq_cg_update_plain(feahip_ctx *c, int it);
-void enq_cg_direction_from(feahip_ctx *c, int it, const double *z);
-void enq_dot_rz(feahip_ctx *c, const double *r, const double *z);
-void enq_cg_init_plain(feahip_ctx *c);
-void enq_cg_init_scalars_plain(feahip_ctx *c, double tol);
-void enq_spmv_pq(feahip_ctx *c);
 
 // ---------------------------------------------------------------------------
 // kernels
@@ -96,9 +90,9 @@ __global__ void k_galerkin(int npair, const int *prow, const int *crowptr, const
 
 // inverse of the diagonal 3x3 blocks; a singular block (aggregate made of
 // prescribed dofs only) gets the identity
-__global__ void k_block_inverse(int N, const int *diag, const double *K, double *minv)
+__global__ void k_block_inverse(int a0, int N, const int *diag, const double *K, double *minv)
 {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  const int a = a0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= N) return;
   double d[9];
   for (int t = 0; t < 9; ++t) d[t] = K[(size_t)diag[a] * 9 + t];
@@ -117,9 +111,9 @@ __global__ void k_block_inverse(int N, const int *diag, const double *K, double 
 }
 
 // x = omega D^-1 r                       (first smoothing sweep from x = 0)
-__global__ void k_smooth_first(int N, double omega, const double *minv, const double *r, double *x)
+__global__ void k_smooth_first(int a0, int N, double omega, const double *minv, const double *r, double *x)
 {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  const int a = a0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= N) return;
   const double *m = minv + (size_t)a * 9;
   const double r0 = r[(size_t)a * 3], r1 = r[(size_t)a * 3 + 1], r2 = r[(size_t)a * 3 + 2];
@@ -127,9 +121,9 @@ __global__ void k_smooth_first(int N, double omega, const double *minv, const do
 }
 
 // x += omega D^-1 (r - y)                (y = K x)
-__global__ void k_smooth_next(int N, double omega, const double *minv, const double *r, const double *y, double *x)
+__global__ void k_smooth_next(int a0, int N, double omega, const double *minv, const double *r, const double *y, double *x)
 {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  const int a = a0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= N) return;
   const double *m = minv + (size_t)a * 9;
   const double t0 = r[(size_t)a * 3] - y[(size_t)a * 3], t1 = r[(size_t)a * 3 + 1] - y[(size_t)a * 3 + 1],
@@ -176,7 +170,7 @@ __global__ void k_prolong(int N, const int *agg, const uint8_t *type_f, const do
                           const uint8_t *mask, double over, double *x)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
+  if (i >= N || agg[i] < 0) return;                     // rows of other ranks have no aggregate here
   const double *c6 = xc + (size_t)agg[i] * 6;
   const size_t k = (size_t)i * 3;
   double u0, u1, u2;
@@ -194,18 +188,18 @@ __global__ void k_prolong(int N, const int *agg, const uint8_t *type_f, const do
 }
 
 // power iteration helpers for lambda_max(D^-1 K)
-__global__ void k_apply_minv(int N, const double *minv, const double *y, double *v)
+__global__ void k_apply_minv(int a0, int N, const double *minv, const double *y, double *v)
 {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  const int a = a0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= N) return;
   const double *m = minv + (size_t)a * 9;
   const double y0 = y[(size_t)a * 3], y1 = y[(size_t)a * 3 + 1], y2 = y[(size_t)a * 3 + 2];
   for (int i = 0; i < 3; ++i) v[(size_t)a * 3 + i] = m[3 * i] * y0 + m[3 * i + 1] * y1 + m[3 * i + 2] * y2;
 }
-__global__ void k_fill_pattern(int n, double *v)
+__global__ void k_fill_pattern(int t0, int t1, int n, double *v)
 {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n) v[t] = 1.0 + 0.37 * (double)((t * 2654435761u) >> 24) / 256.0;      // fixed pseudo-random start
+  if (t < n) v[t] = (t >= t0 && t < t1) ? 1.0 + 0.37 * (double)((t * 2654435761u) >> 24) / 256.0 : 0.0;   // fixed pseudo-random start
 }
 // |v|^2 in two stages with a fixed grid and order (deterministic)
 __global__ __launch_bounds__(256)
@@ -267,12 +261,13 @@ int amg_create(feahip_ctx *c)
     FEA_HIP_CHECK(c, hipMemcpy(pad.data(), c->d_X0, sizeof(double) * pad.size(), hipMemcpyDeviceToHost));
     for (int i = 0; i < c->N; ++i) for (int d = 0; d < 3; ++d) pos[(size_t)i * 3 + d] = pad[(size_t)i * 4 + d];
   }
-  if (!build_host_amg(c->h_rowptr, c->h_colidx, pos, hl)) {
+  if (!build_host_amg(c->h_rowptr, c->h_colidx, pos, c->row0, c->row1, hl)) {
     c->err = "multigrid hierarchy unavailable for this mesh (too small, or a coarse row exceeds the SpMV chunk)";
     return FEAHIP_EINVAL;
   }
   AmgHierarchy *h = new AmgHierarchy();
   c->amg = h;
+  h->row0 = c->row0; h->row1 = c->row1;
   { const char *e = getenv("FEAHIP_AMG_GAMMA"); if (e) h->gamma = atoi(e); }
   { const char *e = getenv("FEAHIP_AMG_OVER"); if (e) h->over = atof(e); }
   { const char *e = getenv("FEAHIP_AMG_GAMMA_FROM"); if (e) h->gamma_from = atoi(e); }
@@ -332,6 +327,18 @@ void amg_destroy(feahip_ctx *c)
 
 #define G256(n) dim3(((n) + 255) / 256 > 0 ? ((n) + 255) / 256 : 1), dim3(256), 0, c->stream
 
+// rows and SpMV chunks a level works on: everything below level 0 is the rank's
+// own; on level 0 the rank's rows of the context's arrays
+struct LevelRange { int a0, a1, ch0, nch; };
+static LevelRange level_range(feahip_ctx *c, int l)
+{
+  AmgHierarchy *h = H(c);
+  const AmgLevel &L = h->lv[l];
+  if (l == 0) return {h->row0, h->row1, c->chunk0, c->nchunks_local};
+  return {0, L.N, 0, L.nchunks};
+}
+#define GROWS(R) G256((R).a1 - (R).a0)
+
 // coarse matrices, block inverses and the Jacobi damping of every level, for the current K
 static int amg_numeric(feahip_ctx *c)
 {
@@ -339,7 +346,8 @@ static int amg_numeric(feahip_ctx *c)
   const int nl = (int)h->lv.size();
   for (int l = 0; l < nl; ++l) {
     AmgLevel &L = h->lv[l];
-    hipLaunchKernelGGL(k_block_inverse, G256(L.N), L.N, L.diag, L.K, L.minv);
+    const LevelRange R = level_range(c, l);
+    hipLaunchKernelGGL(k_block_inverse, GROWS(R), R.a0, R.a1, L.diag, L.K, L.minv);
     if (L.Nc > 0) {
       AmgLevel &C = h->lv[l + 1];
       hipLaunchKernelGGL(k_galerkin, G256(C.nnzb / 4), C.nnzb / 4, L.prow, C.rowptr, L.cbptr, L.cblist, L.K, C.K, L.cbrow, L.colidx,
@@ -348,11 +356,11 @@ static int amg_numeric(feahip_ctx *c)
     // lambda_max(D^-1 K) by a few power iterations -> omega = 4 / (3 lambda_max)
     double *v = (l == 0) ? h->d_pw : L.x, *y = (l == 0) ? c->d_q : L.y;
     const int n = L.N * 3;
-    hipLaunchKernelGGL(k_fill_pattern, G256(n), n, v);
+    hipLaunchKernelGGL(k_fill_pattern, G256(n), 3 * R.a0, 3 * R.a1, n, v);
     double lam = 1.0;
     for (int it = 0; it < 8; ++it) {
-      enq_spmv_arrays(c->stream, L.nchunks, L.chunk, L.rowptr, L.colidx, L.K, v, y);
-      hipLaunchKernelGGL(k_apply_minv, G256(L.N), L.N, L.minv, y, v);
+      enq_spmv_arrays(c->stream, R.ch0, R.nch, L.chunk, L.rowptr, L.colidx, L.K, v, y);
+      hipLaunchKernelGGL(k_apply_minv, GROWS(R), R.a0, R.a1, L.minv, y, v);
       const int nb = n >= 256 * 1024 ? 1024 : (n + 255) / 256;
       hipLaunchKernelGGL(k_norm2_partial, dim3(nb), dim3(256), 0, c->stream, n, v, c->d_part);
       hipLaunchKernelGGL(k_norm2_final, dim3(1), dim3(256), 0, c->stream, nb, c->d_part, c->d_scal + 12);
@@ -381,24 +389,25 @@ static void amg_cycle(feahip_ctx *c, int l, const double *r, double *x, double *
   AmgHierarchy *h = H(c);
   AmgLevel &L = h->lv[l];
   const uint8_t *mask = l == 0 ? c->d_dofmask : (const uint8_t *)nullptr;
-  hipLaunchKernelGGL(k_smooth_first, G256(L.N), L.N, L.omega, L.minv, r, x);
+  const LevelRange R = level_range(c, l);
+  hipLaunchKernelGGL(k_smooth_first, GROWS(R), R.a0, R.a1, L.omega, L.minv, r, x);
   if (L.Nc == 0) {
     for (int s = 0; s < h->coarse_sweeps; ++s) {
-      enq_spmv_arrays(c->stream, L.nchunks, L.chunk, L.rowptr, L.colidx, L.K, x, y);
-      hipLaunchKernelGGL(k_smooth_next, G256(L.N), L.N, L.omega, L.minv, r, y, x);
+      enq_spmv_arrays(c->stream, R.ch0, R.nch, L.chunk, L.rowptr, L.colidx, L.K, x, y);
+      hipLaunchKernelGGL(k_smooth_next, GROWS(R), R.a0, R.a1, L.omega, L.minv, r, y, x);
     }
     return;
   }
   AmgLevel &C = h->lv[l + 1];
   const int gamma = (l < h->gamma_from) ? 1 : h->gamma;
   for (int g = 0; g < gamma; ++g) {
-    enq_spmv_arrays(c->stream, L.nchunks, L.chunk, L.rowptr, L.colidx, L.K, x, y);
+    enq_spmv_arrays(c->stream, R.ch0, R.nch, L.chunk, L.rowptr, L.colidx, L.K, x, y);
     hipLaunchKernelGGL(k_restrict, G256((C.N / 2) * 16), C.N / 2, L.aptr, L.anodes, L.type, L.doff, r, y, mask, C.r);
     amg_cycle(c, l + 1, C.r, C.x, C.y);
     hipLaunchKernelGGL(k_prolong, G256(L.N), L.N, L.agg, L.type, L.doff, C.x, mask, h->over, x);
   }
-  enq_spmv_arrays(c->stream, L.nchunks, L.chunk, L.rowptr, L.colidx, L.K, x, y);
-  hipLaunchKernelGGL(k_smooth_next, G256(L.N), L.N, L.omega, L.minv, r, y, x);
+  enq_spmv_arrays(c->stream, R.ch0, R.nch, L.chunk, L.rowptr, L.colidx, L.K, x, y);
+  hipLaunchKernelGGL(k_smooth_next, GROWS(R), R.a0, R.a1, L.omega, L.minv, r, y, x);
 }
 
 static void amg_vcycle(feahip_ctx *c, const double *r0, double *z0)
@@ -406,51 +415,22 @@ static void amg_vcycle(feahip_ctx *c, const double *r0, double *z0)
   amg_cycle(c, 0, r0, z0, c->d_q);
 }
 
-// PCG with the V-cycle as preconditioner (single rank).  Same recurrences,
-// device scalars and stop test as the block-Jacobi solver in kernels_solve.hip.
-int solve_pcg_amg(feahip_ctx *c, double tol, int max_iter, int *iters, double *resid)
+// ---- interface to the PCG loop (kernels_solve.hip) ---------------------------
+// hierarchy for the context's current row range + numeric setup for the current K
+int amg_prepare(feahip_ctx *c)
 {
   int rc;
-  if ((rc = amg_create(c))) return rc;
-  if ((rc = amg_numeric(c))) return rc;
   AmgHierarchy *h = H(c);
-  FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_u, c->d_f, sizeof(double) * (size_t)c->ndof, hipMemcpyDeviceToDevice, c->stream));
-  enq_cg_init_plain(c);                         // r = f - K u0, partial r.r and b.b (p, r.z placeholders)
-  amg_vcycle(c, c->d_r, h->d_z);
-  enq_dot_rz(c, c->d_r, h->d_z);
-  enq_cg_init_scalars_plain(c, tol);
-  FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_p, h->d_z, sizeof(double) * (size_t)c->ndof, hipMemcpyDeviceToDevice, c->stream));
-  FEA_HIP_CHECK(c, hipGetLastError());
-  int flag = 0, it = 0;
-  const int batch = 8;
-  while (it < max_iter) {
-    const int n = (max_iter - it < batch) ? (max_iter - it) : batch;
-    for (int k = 0; k < n; ++k) {
-      enq_spmv_pq(c);                           // q = K p, partial p.q
-      enq_cg_update_plain(c, it + k);           // x += alpha p, r -= alpha q, partial r.r
-      amg_vcycle(c, c->d_r, h->d_z);            // z = V(r)   (uses q as scratch: q is dead after the update)
-      enq_dot_rz(c, c->d_r, h->d_z);            // partial r.z
-      enq_cg_direction_from(c, it + k, h->d_z); // beta, p = z + beta p, stop test
-    }
-    it += n;
-    FEA_HIP_CHECK(c, hipGetLastError());
-    FEA_HIP_CHECK(c, hipMemcpyAsync(&flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    if (flag != 0) break;
-  }
-  double sc[5];
-  FEA_HIP_CHECK(c, hipMemcpyAsync(sc, c->d_scal, sizeof(sc), hipMemcpyDeviceToHost, c->stream));
-  FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-  int done_it = it;
-  if (flag == -1000000000) done_it = 0;
-  else if (flag > 0) done_it = flag;
-  else if (flag < 0) done_it = -flag;
-  if (iters) *iters = done_it;
-  if (resid) *resid = (sc[2] > 0) ? sqrt(sc[3] / sc[2]) : sqrt(sc[3]);
-  FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
-  if (flag < 0 && flag != -1000000000) {
-    c->err = "multigrid PCG breakdown at iteration " + std::to_string(-flag);
-    return FEAHIP_ENOTCONVERGED;
-  }
-  return FEAHIP_OK;
+  if (h && (h->row0 != c->row0 || h->row1 != c->row1)) { amg_destroy(c); h = nullptr; }     // the shard changed
+  if (!h && (rc = amg_create(c))) return rc;
+  return amg_numeric(c);
+}
+
+// z = M^-1 r on the rank's rows (z stays zero elsewhere); q is used as scratch
+double *amg_result(feahip_ctx *c) { return H(c)->d_z; }
+double *amg_apply(feahip_ctx *c, const double *r)
+{
+  AmgHierarchy *h = H(c);
+  amg_vcycle(c, r, h->d_z);
+  return h->d_z;
 }

@@ -68,8 +68,48 @@ void finish_pattern(HostAmgLevel &L)
 // Level 0: one block row per mesh node ("site"), all of translation type.
 // Level l >= 1: two block rows per site (aggregate of the level above): its
 // translation and its rotation about the aggregate's centroid.
-bool build_host_amg(const std::vector<int> &rowptr0, const std::vector<int> &colidx0, const std::vector<double> &pos0,
-                    std::vector<HostAmgLevel> &out)
+//
+// A rank of a sharded solve builds the hierarchy of ITS diagonal block: nodes
+// [own0, own1) and the couplings among them.  Level 0 keeps the global
+// numbering of the context's arrays (nodes outside the range have agg = -1 and
+// appear in no list); everything below is local to the rank, so the
+// preconditioner -- block-Jacobi over the ranks, a W-cycle inside each --
+// needs no communication.
+static bool build_levels(const std::vector<int> &rowptr0, const std::vector<int> &colidx0, const std::vector<double> &pos0,
+                         std::vector<HostAmgLevel> &out);
+
+bool build_host_amg(const std::vector<int> &rowptr, const std::vector<int> &colidx, const std::vector<double> &pos,
+                    int own0, int own1, std::vector<HostAmgLevel> &out)
+{
+  const int N = (int)rowptr.size() - 1, nloc = own1 - own0;
+  if (own0 == 0 && own1 == N) return build_levels(rowptr, colidx, pos, out);
+  // the rank's diagonal block as a graph of its own
+  std::vector<int> lrow((size_t)nloc + 1, 0), lcol, lq;
+  for (int i = own0; i < own1; ++i) {
+    for (int q = rowptr[i]; q < rowptr[i + 1]; ++q)
+      if (colidx[q] >= own0 && colidx[q] < own1) { lcol.push_back(colidx[q] - own0); lq.push_back(q); }
+    lrow[i - own0 + 1] = (int)lcol.size();
+  }
+  std::vector<double> lpos(pos.begin() + (size_t)own0 * 3, pos.begin() + (size_t)own1 * 3);
+  if (!build_levels(lrow, lcol, lpos, out)) return false;
+  // level 0 back to the numbering of the context's arrays
+  HostAmgLevel &L = out[0];
+  std::vector<int> agg((size_t)N, -1), cbrow((size_t)rowptr[N], -1);
+  std::vector<double> doff((size_t)N * 3, 0.0);
+  for (int i = 0; i < nloc; ++i) {
+    agg[own0 + i] = L.agg[i];
+    for (int d = 0; d < 3; ++d) doff[(size_t)(own0 + i) * 3 + d] = L.doff[(size_t)i * 3 + d];
+  }
+  for (size_t k = 0; k < L.cbrow.size(); ++k) cbrow[lq[k]] = L.cbrow[k] + own0;
+  for (int &v : L.anodes) v += own0;
+  for (int &v : L.cblist) v = lq[v];
+  L.agg.swap(agg); L.doff.swap(doff); L.cbrow.swap(cbrow);
+  L.N = N; L.S = N;                      // the device loops over the context's rows; rows without an aggregate are skipped
+  return true;
+}
+
+static bool build_levels(const std::vector<int> &rowptr0, const std::vector<int> &colidx0, const std::vector<double> &pos0,
+                         std::vector<HostAmgLevel> &out)
 {
   out.clear();
   HostAmgLevel L;

@@ -128,9 +128,7 @@ int dist_newton(std::vector<feahip_ctx *> &R, int load_increments, int max_newto
         EACH(feahip_create_stiffness_and_residual(c));                // :185 + :200
       }
       EACH(feahip_apply_prescribed_bc(c, 0.0));                       // :203
-      if (R.size() == 1) {                                            // :205 (single rank: the context's preconditioner choice applies)
-        if ((rc = feahip_solve_slae(R[0], solver_type, solver_tolerance, solver_max_iter, nullptr, nullptr))) return rc;
-      } else if ((rc = dist_solve_pcg(R, solver_type, solver_tolerance, solver_max_iter, nullptr, nullptr))) return rc;
+      if ((rc = dist_solve_pcg(R, solver_type, solver_tolerance, solver_max_iter, nullptr, nullptr))) return rc;  // :205
       if ((rc = dist_energy(R, &tolerance))) return rc;               // :208-210, identical on every rank
       if (tol_log && nlog < tol_log_cap) tol_log[nlog] = tolerance;
       nlog++;

@@ -314,11 +314,7 @@ extern "C" int feahip_solve_slae(feahip_ctx *c, int type, double tol, int max_it
   CTX_GUARD(c);
   if (type < FEAHIP_CG || type > FEAHIP_CHOLESKY) { c->err = "unknown solver type"; return FEAHIP_EINVAL; }
   if (max_iter <= 0) { c->err = "max_iterations must be positive"; return FEAHIP_EINVAL; }
-  if (c->precond == 1 && type != FEAHIP_CG && c->nranks == 1) {
-    if (type == FEAHIP_CHOLESKY) { tol = 1e-16; if (max_iter < 100000) max_iter = 100000; }
-    return solve_pcg_amg(c, tol, max_iter, iters, resid);
-  }
-  return solve_pcg(c, type, tol, max_iter, iters, resid);
+  return solve_pcg(c, type, tol, max_iter, iters, resid);    // block-Jacobi or multigrid by the context's setting
 }
 
 extern "C" int feahip_energy(feahip_ctx *c, double *tolerance)

@@ -277,6 +277,12 @@ void k_reduce_final(int n, int nsums, int stride, const double *part, double *ou
 // ------------------------------------------------------------------------
 #define RB FEA_RED_BLOCKS
 
+// multigrid preconditioner (amg.hip); used when the context asks for it and the solve is not plain CG
+int amg_prepare(feahip_ctx *c);
+double *amg_apply(feahip_ctx *c, const double *r);
+double *amg_result(feahip_ctx *c);
+static inline bool use_amg(const feahip_ctx *c, int mode) { return mode != 0 && c->precond == 1; }
+
 // 3x3 inverse of the diagonal blocks (block-Jacobi); mode 0 = identity
 __global__ void k_precond_build(int a0, int a1, const int *diag, const double *K, int mode, double *minv)
 {
@@ -541,7 +547,7 @@ Transport *make_group_transport() { return new GroupTransport(); }
 // ------------------------------------------------------------------------
 #define FOR_RANKS(c) for (feahip_ctx *c : R) if (hipSetDevice(c->device) == hipSuccess)
 
-static int enq_cg_iteration(std::vector<feahip_ctx *> &R, Transport *T, int it)
+static int enq_cg_iteration(std::vector<feahip_ctx *> &R, Transport *T, int it, int mode)
 {
   int rc;
   if (T && (rc = T->exchange(R, 0))) return rc;                  // halo rows of p
@@ -552,17 +558,24 @@ static int enq_cg_iteration(std::vector<feahip_ctx *> &R, Transport *T, int it)
   if (T && (rc = T->allreduce(R, 0, 1))) return rc;              // p.q
   FOR_RANKS(c) {
     const int gv = vgrid(c);
+    const bool amg = use_amg(c, mode);
+    // block-Jacobi: z = M r is formed here and left in q; multigrid: plain update, then the cycle
     hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(256), 0, c->stream, own0(c), own1(c), it, spmv_grid(c), c->d_p,
-                       c->d_q, c->d_minv, c->d_u, c->d_r, c->d_part, T ? c->d_scal + 8 : (const double *)nullptr,
-                       c->d_scal, c->d_flag, c->d_q);
+                       c->d_q, amg ? (const double *)nullptr : c->d_minv, c->d_u, c->d_r, c->d_part,
+                       T ? c->d_scal + 8 : (const double *)nullptr, c->d_scal, c->d_flag, amg ? (double *)nullptr : c->d_q);
+    if (amg) {
+      const double *z = amg_apply(c, c->d_r);                      // local: block-Jacobi over the ranks, a W-cycle inside
+      hipLaunchKernelGGL(k_dot_partial, dim3(gv), dim3(256), 0, c->stream, 3 * own0(c), 3 * own1(c), c->d_r, z, c->d_part + RB);
+    }
     if (T) hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, gv, 2, RB, c->d_part + RB, c->d_scal + 9);
   }
   if (T && (rc = T->allreduce(R, 1, 2))) return rc;              // r.z, r.r
   FOR_RANKS(c) {
     const int gv = vgrid(c);
-    hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(256), 0, c->stream, own0(c), own1(c), it, gv, c->d_q,
+    const double *z = use_amg(c, mode) ? amg_result(c) : c->d_q;
+    hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(256), 0, c->stream, own0(c), own1(c), it, gv, z,
                        (const double *)nullptr, c->d_p, c->d_part, T ? c->d_scal + 9 : (const double *)nullptr, c->d_scal,
-                       c->d_flag);                                  // z = M r is in q since k_cg_update
+                       c->d_flag);
   }
   return FEAHIP_OK;
 }
@@ -571,15 +584,23 @@ static int enq_cg_start(std::vector<feahip_ctx *> &R, Transport *T, int mode, do
 {
   int rc;
   FOR_RANKS(c) {
-    enq_precond(c, mode);
+    if (use_amg(c, mode)) { if ((rc = amg_prepare(c))) return rc; }
+    else enq_precond(c, mode);
     FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_u, c->d_f, sizeof(double) * (size_t)c->ndof, hipMemcpyDeviceToDevice, c->stream));
   }
   if (T && (rc = T->exchange(R, 1))) return rc;                  // halo rows of u0 = f
   FOR_RANKS(c) {
     const int gv = vgrid(c);
+    const bool amg = use_amg(c, mode);
     enq_spmv_dot(c, c->d_u, c->d_q, nullptr, nullptr);
-    hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(256), 0, c->stream, own0(c), own1(c), c->d_f, c->d_q, c->d_minv,
-                       c->d_r, c->d_p, c->d_part);
+    hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(256), 0, c->stream, own0(c), own1(c), c->d_f, c->d_q,
+                       amg ? (const double *)nullptr : c->d_minv, c->d_r, c->d_p, c->d_part);
+    if (amg) {                                                   // p = z = M^-1 r from the cycle, r.z from it
+      const double *z = amg_apply(c, c->d_r);
+      hipLaunchKernelGGL(k_dot_partial, dim3(gv), dim3(256), 0, c->stream, 3 * own0(c), 3 * own1(c), c->d_r, z, c->d_part + RB);
+      FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_p + (size_t)3 * own0(c), z + (size_t)3 * own0(c),
+                                      sizeof(double) * 3 * (size_t)(own1(c) - own0(c)), hipMemcpyDeviceToDevice, c->stream));
+    }
     if (T) hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, c->stream, gv, 3, RB, c->d_part + RB, c->d_scal + 8);
   }
   if (T && (rc = T->allreduce(R, 0, 3))) return rc;              // r.z, r.r, b.b
@@ -602,11 +623,11 @@ int dist_solve_pcg(std::vector<feahip_ctx *> &R, int type, double tol, int max_i
   int rc = enq_cg_start(R, T, mode, tol);
   if (rc) return rc;
   int flag = 0, it = 0;
-  const int batch = 32;
+  const int batch = use_amg(c0, mode) ? 8 : 32;
   while (it < max_iter) {
     const int n = (max_iter - it < batch) ? (max_iter - it) : batch;
     for (int k = 0; k < n; ++k)
-      if ((rc = enq_cg_iteration(R, T, it + k))) return rc;
+      if ((rc = enq_cg_iteration(R, T, it + k, mode))) return rc;
     it += n;
     (void)hipSetDevice(c0->device);
     FEA_HIP_CHECK(c0, hipGetLastError());
@@ -711,9 +732,9 @@ int time_pcg_iteration(feahip_ctx *c, int warmup, int iters, double *avg_ms)
   hipEvent_t e0, e1;
   FEA_HIP_CHECK(c, hipEventCreate(&e0));
   FEA_HIP_CHECK(c, hipEventCreate(&e1));
-  for (int k = 0; k < warmup; ++k) if ((rc = enq_cg_iteration(R, T, k))) return rc;
+  for (int k = 0; k < warmup; ++k) if ((rc = enq_cg_iteration(R, T, k, 1))) return rc;
   FEA_HIP_CHECK(c, hipEventRecord(e0, c->stream));
-  for (int k = 0; k < iters; ++k) if ((rc = enq_cg_iteration(R, T, warmup + k))) return rc;
+  for (int k = 0; k < iters; ++k) if ((rc = enq_cg_iteration(R, T, warmup + k, 1))) return rc;
   FEA_HIP_CHECK(c, hipEventRecord(e1, c->stream));
   FEA_HIP_CHECK(c, hipEventSynchronize(e1));
   float ms = 0;
@@ -725,43 +746,12 @@ int time_pcg_iteration(feahip_ctx *c, int warmup, int iters, double *avg_ms)
 }
 
 // y = K x on any level of a hierarchy (amg.hip): same kernel, explicit arrays
-void enq_spmv_arrays(hipStream_t stream, int nchunks, const int *chunk, const int *rowptr, const int *colidx,
+void enq_spmv_arrays(hipStream_t stream, int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx,
                      const double *K, const double *xv, double *yv)
 {
   int g = (nchunks + FEA_WAVES_PER_WG - 1) / FEA_WAVES_PER_WG;
   g = g < FEA_RED_BLOCKS ? (g > 0 ? g : 1) : FEA_RED_BLOCKS;
-  hipLaunchKernelGGL(k_spmv, dim3(g), dim3(256), 0, stream, 0, nchunks, chunk, rowptr, colidx, K, xv, yv,
+  hipLaunchKernelGGL(k_spmv, dim3(g), dim3(256), 0, stream, chunk0, nchunks, chunk, rowptr, colidx, K, xv, yv,
                      (const double *)nullptr, (double *)nullptr, (const int *)nullptr);
 }
 
-// pieces of the PCG loop reused by the multigrid-preconditioned solve (amg.hip)
-void enq_cg_update_plain(feahip_ctx *c, int it)
-{
-  hipLaunchKernelGGL(k_cg_update, dim3(vgrid(c)), dim3(256), 0, c->stream, own0(c), own1(c), it, spmv_grid(c), c->d_p,
-                     c->d_q, (const double *)nullptr, c->d_u, c->d_r, c->d_part, (const double *)nullptr, c->d_scal, c->d_flag,
-                     (double *)nullptr);
-}
-void enq_cg_direction_from(feahip_ctx *c, int it, const double *z)
-{
-  const int gv = vgrid(c);
-  hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(256), 0, c->stream, own0(c), own1(c), it, gv, z, (const double *)nullptr,
-                     c->d_p, c->d_part, (const double *)nullptr, c->d_scal, c->d_flag);
-}
-void enq_dot_rz(feahip_ctx *c, const double *r, const double *z)
-{
-  // same grid as the vector kernels: overwrites exactly the r.z partials k_cg_direction sums
-  hipLaunchKernelGGL(k_dot_partial, dim3(vgrid(c)), dim3(256), 0, c->stream, 3 * own0(c), 3 * own1(c), r, z, c->d_part + RB);
-}
-void enq_cg_init_plain(feahip_ctx *c)
-{
-  const int gv = vgrid(c);
-  enq_spmv_dot(c, c->d_u, c->d_q, nullptr, nullptr);
-  hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(256), 0, c->stream, own0(c), own1(c), c->d_f, c->d_q, (const double *)nullptr,
-                     c->d_r, c->d_p, c->d_part);
-}
-void enq_cg_init_scalars_plain(feahip_ctx *c, double tol)
-{
-  hipLaunchKernelGGL(k_cg_init_scalars, dim3(1), dim3(256), 0, c->stream, vgrid(c), c->d_part, (const double *)nullptr,
-                     c->d_scal, tol, c->d_flag);
-}
-void enq_spmv_pq(feahip_ctx *c) { enq_spmv_dot(c, c->d_p, c->d_q, c->d_p, c->d_part); }

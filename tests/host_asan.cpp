@@ -34,7 +34,15 @@ int main()
       printf("tet10: N=%d E=%d chunks=%zu achunks=%zu quad=%d pairs=%zu\n", N, E, hp.chunk.size() - 1, hp.achunk.size() - 1, (int)hq.ok, hq.qpair.size());
     }
     std::vector<HostAmgLevel> lv;
-    const bool ok = build_host_amg(hp.rowptr, hp.colidx, pos, lv);
+    const bool ok = build_host_amg(hp.rowptr, hp.colidx, pos, 0, N, lv);
+    {                                       // a rank's diagonal block: rows of the middle third
+      std::vector<HostAmgLevel> part;
+      const bool okp = build_host_amg(hp.rowptr, hp.colidx, pos, N / 3, 2 * N / 3, part);
+      long long inside = 0;
+      if (okp) for (int i = 0; i < N; ++i) inside += part[0].agg[i] >= 0 ? 1 : 0;
+      printf("  amg shard [%d,%d): ok=%d levels=%zu rows with an aggregate %lld\n", N / 3, 2 * N / 3, (int)okp, part.size(), inside);
+      if (okp && inside != 2 * N / 3 - N / 3) return 2;
+    }
     printf("  amg: ok=%d levels=%zu", (int)ok, lv.size());
     for (auto &L : lv) printf(" [N=%d S=%d Sc=%d nnzb=%zu]", L.N, L.S, L.Sc, L.colidx.size());
     printf("\n");

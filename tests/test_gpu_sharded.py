@@ -84,6 +84,37 @@ def test_sharded_full_newton_patch_test():
     g.close()
 
 
+@pytest.mark.parametrize("n", [2, 3])
+def test_sharded_multigrid_preconditioner(n):
+    """Sharded solve with feahip_set_preconditioner(1): every rank runs the
+    W-cycle on its own diagonal block (block-Jacobi over the ranks, no
+    communication inside the preconditioner).  Same solution as the unsharded
+    block-Jacobi solve, far fewer iterations than sharded block-Jacobi, and a
+    sharded Newton step lands where the unsharded one does."""
+    deck = mesh.bar_deck(dims=(6, 126, 6))
+    one = feahip.FeaSolver(deck)
+    one.update_nodes_with_bc(1.0); one.create_stiffness_and_residual(); one.apply_prescribed_bc(0.0)
+    it_bj, _ = one.solve_slae(feahip.PCG_ILU, 1e-15, 40000)
+    g = feahip.FeaGroup(deck, n)
+    g.each("set_preconditioner", 1)
+    g.each("update_nodes_with_bc", 1.0); g.each("create_stiffness_and_residual"); g.each("apply_prescribed_bc", 0.0)
+    it_mg, res = g.solve_slae(feahip.PCG_ILU, 1e-15, 40000)
+    assert res < 1e-14 and 0 < it_mg < 0.5 * it_bj
+    assert rel(g.gather("solution"), one.solution()) < 1e-10
+    assert g.energy() == pytest.approx(one.energy(), rel=1e-10)
+    g.close(); one.close()
+    deck = mesh.bar_deck(dims=(6, 126, 6), dy=0.01, load_increments_count=1, max_newton_count=12, modified_newton=False,
+                         desired_tolerance=1e-16)
+    a = feahip.FeaSolver(deck)
+    ra = a.solve(solver_type=feahip.PCG_ILU, solver_tolerance=1e-15)
+    g = feahip.FeaGroup(deck, n)
+    g.each("set_preconditioner", 1)
+    gd, gits, gtol = g.solve(1, 12, deck.modified_newton, deck.desired_tolerance, feahip.PCG_ILU, 1e-15)
+    assert gd == ra[0] == 1 and list(gits) == list(ra[1])
+    assert rel(g.gather("nodes") - deck.nodes, a.nodes() - deck.nodes) < 1e-10
+    g.close(); a.close()
+
+
 def test_rccl_single_rank_comm():
     """RCCL transport with one rank (all this box can host): unique id,
     communicator, all-reduce of the CG scalars, empty halo exchange."""
