@@ -36,7 +36,8 @@ struct VisitArgs {
   unsigned long long *stamps;    // [chunk][8] s_memtime stamps when dbg & 4
 };
 
-template <bool DOK, bool DOF>
+// DBG: the timing experiments of DESIGN.md section 4 (FEAHIP_DBG); the production instantiations carry none of it
+template <bool DOK, bool DOF, bool DBG>
 __global__ __launch_bounds__(64)
 void k_assemble_visit(VisitArgs A)
 {
@@ -47,7 +48,7 @@ void k_assemble_visit(VisitArgs A)
   __shared__ int sDiag[FEA_CHUNK_ROWS];
   const int lane = threadIdx.x;
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
-  if (A.dbg & 4) t0 = __builtin_amdgcn_s_memtime();
+  if (DBG && A.dbg & 4) t0 = __builtin_amdgcn_s_memtime();
   // node lists have a fixed stride per chunk, so they are fetched together with
   // the descriptor (one dependent latency less); unused tail entries are 0
   // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so
@@ -56,7 +57,7 @@ void k_assemble_visit(VisitArgs A)
   // from the same L2 (placement is a speed matter only).
   const int nwg = gridDim.x, per = (nwg + 7) >> 3;
   int cidx = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if (A.dbg & 8) cidx = blockIdx.x;
+  if (DBG && A.dbg & 8) cidx = blockIdx.x;
   if (cidx >= A.nchunks) return;   // the grid is padded to a multiple of 8
   const int chunk = A.chunk0 + cidx;
   const int vn0 = A.vnode[(size_t)chunk * FEA_VISIT_MAX_NODES + lane];
@@ -85,7 +86,7 @@ void k_assemble_visit(VisitArgs A)
   if (DOF)
     for (int t = lane; t < 4 * (FEA_CHUNK_ROWS * 3 + 3); t += 64) (&sF[0][0])[t] = 0.0;
   __syncthreads();
-  if (A.dbg & 4) t1 = __builtin_amdgcn_s_memtime();
+  if (DBG && A.dbg & 4) t1 = __builtin_amdgcn_s_memtime();
 
   for (int p = lane; p - lane < d.nvisit; p += 64) {
     // record of the next pass, in flight while this one computes
@@ -115,7 +116,7 @@ void k_assemble_visit(VisitArgs A)
         const double ga[3] = {s.g[0][0], s.g[0][1], s.g[0][2]};
         RowVecs rv;
         row_vectors(ga, s.sig, s.l1, s.m1, s.vol, rv);
-        if (DOF && !(A.dbg & 2)) {
+        if (DOF && !(DBG && A.dbg & 2)) {
 #pragma unroll
           for (int i = 0; i < 3; ++i)
             __hip_atomic_fetch_add(&sF[lane & 3][n0 * 3 + i], -rv.s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -127,7 +128,7 @@ void k_assemble_visit(VisitArgs A)
             double blk[9];
             block_row(rv, s.g[k], blk);
             double *dst = sKt + rowoff + (int)((sl >> (8 * k)) & 255u) * 9;
-            if (A.dbg & 1) dst = sKt + lane * 9;
+            if (DBG && A.dbg & 1) dst = sKt + lane * 9;
 #pragma unroll
             for (int q = 0; q < 9; ++q)
               __hip_atomic_fetch_add(dst + q, blk[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -138,7 +139,7 @@ void k_assemble_visit(VisitArgs A)
     rec = nxt;
   }
   __syncthreads();
-  if (A.dbg & 4) t2 = __builtin_amdgcn_s_memtime();
+  if (DBG && A.dbg & 4) t2 = __builtin_amdgcn_s_memtime();
 
   if (DOK) {
     // K_aa = -sum_{b != a} K_ab (shape functions sum to one).  The diagonal
@@ -156,7 +157,7 @@ void k_assemble_visit(VisitArgs A)
       sKt[kd * 9 + q] = -((a0 + a1) + (a2 + a3));
     }
     __syncthreads();
-    if (A.dbg & 4) t3 = __builtin_amdgcn_s_memtime();
+    if (DBG && A.dbg & 4) t3 = __builtin_amdgcn_s_memtime();
     // stream the finished rows out: 16-byte LDS reads and HBM stores
     double *Kd = A.K + (size_t)d.b0 * 9;
     const int total = d.nb * 9;
@@ -172,7 +173,7 @@ void k_assemble_visit(VisitArgs A)
     double *fd = A.f + (size_t)d.r0 * 3;
     for (int t = lane; t < nrows * 3; t += 64) fd[t] = (sF[0][t] + sF[1][t]) + (sF[2][t] + sF[3][t]);
   }
-  if (A.dbg & 4) {
+  if (DBG && A.dbg & 4) {
     __builtin_amdgcn_s_waitcnt(0);
     t4 = __builtin_amdgcn_s_memtime();
     if (lane == 0) {
@@ -225,7 +226,7 @@ __device__ __forceinline__ unsigned lds_addr(const void *p)
 #define FEA_LDS_ORDER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define FEA_VMEM_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-template <bool DOK, bool DOF>
+template <bool DOK, bool DOF, bool DBG>
 __global__ __launch_bounds__(64)
 void k_assemble_run(VisitArgs A, int run_len)
 {
@@ -272,7 +273,7 @@ void k_assemble_run(VisitArgs A, int run_len)
 
   unsigned long long a_rounds = 0, a_tail = 0, a_drain = 0, ta = 0, tb = 0, tc = 0, td = 0;
   for (;;) {
-    if (A.dbg & 4) ta = __builtin_amdgcn_s_memtime();
+    if (DBG && (A.dbg & 4)) ta = __builtin_amdgcn_s_memtime();
     const bool more = chunk + 1 < cend;
     const int nrows = d.r1 - d.r0;
     const int odd = d.b0 & 1;            // LDS and HBM agree on 16-byte alignment in the write-out
@@ -330,7 +331,7 @@ void k_assemble_run(VisitArgs A, int run_len)
               double blk[9];
               block_row(rv, s.g[k], blk);
               double *dst = sKt + rowoff + (int)((sl >> (8 * k)) & 255u) * 9;
-              if (A.dbg & 1) dst = sKt + lane * 9;
+              if (DBG && (A.dbg & 1)) dst = sKt + lane * 9;
 #pragma unroll
               for (int q = 0; q < 9; ++q)
                 __hip_atomic_fetch_add(dst + q, blk[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -342,7 +343,7 @@ void k_assemble_run(VisitArgs A, int run_len)
     }
     // every read of the coordinate tile has returned, and so has the descriptor
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dnv) : : "memory");
-    if (A.dbg & 4) tb = __builtin_amdgcn_s_memtime();
+    if (DBG && (A.dbg & 4)) tb = __builtin_amdgcn_s_memtime();
     VisitDesc dn;
     dn.r0 = dnv[0]; dn.r1 = dnv[1]; dn.b0 = dnv[2]; dn.nb = dnv[3];
     dn.node_off = dnv[4]; dn.nnode = dnv[5]; dn.visit_off = dnv[6]; dn.nvisit = dnv[7];
@@ -398,7 +399,7 @@ void k_assemble_run(VisitArgs A, int run_len)
         sF[0][t] = 0.0; sF[1][t] = 0.0;
       }
     }
-    if (A.dbg & 4) { FEA_LDS_ORDER(); tc = __builtin_amdgcn_s_memtime(); a_rounds += tb - ta; a_tail += tc - tb; }
+    if (DBG && (A.dbg & 4)) { FEA_LDS_ORDER(); tc = __builtin_amdgcn_s_memtime(); a_rounds += tb - ta; a_tail += tc - tb; }
     if (!more) break;
     FEA_LDS_ORDER();
     {
@@ -408,11 +409,11 @@ void k_assemble_run(VisitArgs A, int run_len)
     }
     FEA_VMEM_DRAIN();                    // the coordinate tile of the next chunk has landed
     FEA_LDS_ORDER();
-    if (A.dbg & 4) { td = __builtin_amdgcn_s_memtime(); a_drain += td - tc; }
+    if (DBG && (A.dbg & 4)) { td = __builtin_amdgcn_s_memtime(); a_drain += td - tc; }
     d = dn;
     ++chunk;
   }
-  if ((A.dbg & 4) && lane == 0) {
+  if (DBG && (A.dbg & 4) && lane == 0) {
     unsigned long long *o = A.stamps + (size_t)ridx * 8;
     o[0] = a_rounds; o[1] = a_tail; o[2] = a_drain; o[3] = 0; o[4] = a_rounds + a_tail + a_drain;
   }
@@ -435,9 +436,15 @@ int launch_assemble_visit(feahip_ctx *c, bool doK, bool doF, bool pipelined)
   if (pipelined && !(A.dbg & ~5)) {
     const int nruns = (c->nachunks_local + run_len - 1) / run_len;
     const dim3 rgrid((nruns + 7) & ~7), rblk(64);
-    if (doK && doF) hipLaunchKernelGGL((k_assemble_run<true, true>), rgrid, rblk, 0, c->stream, A, run_len);
-    else if (doK)   hipLaunchKernelGGL((k_assemble_run<true, false>), rgrid, rblk, 0, c->stream, A, run_len);
-    else            hipLaunchKernelGGL((k_assemble_run<false, true>), rgrid, rblk, 0, c->stream, A, run_len);
+    if (A.dbg) {
+      if (doK && doF) hipLaunchKernelGGL((k_assemble_run<true, true, true>), rgrid, rblk, 0, c->stream, A, run_len);
+      else if (doK)   hipLaunchKernelGGL((k_assemble_run<true, false, true>), rgrid, rblk, 0, c->stream, A, run_len);
+      else            hipLaunchKernelGGL((k_assemble_run<false, true, true>), rgrid, rblk, 0, c->stream, A, run_len);
+    } else {
+      if (doK && doF) hipLaunchKernelGGL((k_assemble_run<true, true, false>), rgrid, rblk, 0, c->stream, A, run_len);
+      else if (doK)   hipLaunchKernelGGL((k_assemble_run<true, false, false>), rgrid, rblk, 0, c->stream, A, run_len);
+      else            hipLaunchKernelGGL((k_assemble_run<false, true, false>), rgrid, rblk, 0, c->stream, A, run_len);
+    }
     FEA_HIP_CHECK(c, hipGetLastError());
     if (A.dbg & 4) {                                  // diagnostic path: phase shares, never a timing
       static int printed = 0;
@@ -455,9 +462,15 @@ int launch_assemble_visit(feahip_ctx *c, bool doK, bool doF, bool pipelined)
     return FEAHIP_OK;
   }
   const dim3 grid((c->nachunks_local + 7) & ~7), blk(64);
-  if (doK && doF) hipLaunchKernelGGL((k_assemble_visit<true, true>), grid, blk, 0, c->stream, A);
-  else if (doK)   hipLaunchKernelGGL((k_assemble_visit<true, false>), grid, blk, 0, c->stream, A);
-  else            hipLaunchKernelGGL((k_assemble_visit<false, true>), grid, blk, 0, c->stream, A);
+  if (A.dbg) {
+    if (doK && doF) hipLaunchKernelGGL((k_assemble_visit<true, true, true>), grid, blk, 0, c->stream, A);
+    else if (doK)   hipLaunchKernelGGL((k_assemble_visit<true, false, true>), grid, blk, 0, c->stream, A);
+    else            hipLaunchKernelGGL((k_assemble_visit<false, true, true>), grid, blk, 0, c->stream, A);
+  } else {
+    if (doK && doF) hipLaunchKernelGGL((k_assemble_visit<true, true, false>), grid, blk, 0, c->stream, A);
+    else if (doK)   hipLaunchKernelGGL((k_assemble_visit<true, false, false>), grid, blk, 0, c->stream, A);
+    else            hipLaunchKernelGGL((k_assemble_visit<false, true, false>), grid, blk, 0, c->stream, A);
+  }
   FEA_HIP_CHECK(c, hipGetLastError());
   if (A.dbg & 4) {                                  // diagnostic build path: phase shares, never a timing
     static int printed = 0;
