@@ -185,7 +185,7 @@ struct VisitDesc {                   // 32 bytes, one per chunk
 struct HostVisits {
   std::vector<VisitDesc> desc;
   std::vector<int> vnode;
-  std::vector<uint32_t> vrec;        // [2 * visits]: ids (4 x u8), slots (u8: 0, s1, s2, s3)
+  std::vector<uint32_t> vrec;        // [2 * visits]: ids (4 x u8), then u8 x 4: parity flag, tile positions of the 3 blocks
   bool ok = false;
 };
 void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, HostVisits &out);

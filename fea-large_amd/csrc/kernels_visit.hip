@@ -10,8 +10,8 @@
 // latencies per chunk against ~2 us of arithmetic, so the wave sits stalled.
 // Here the host has prepared, per chunk,
 //   vnode : the nodes its elements touch, owned rows first  (coalesced read)
-//   vrec  : per visit 4 chunk-local node ids, row node first, and the 3
-//           column slots                              (8 B, coalesced read)
+//   vrec  : per visit 4 chunk-local node ids, row node first, and the tile
+//           positions of its 3 blocks                 (8 B, coalesced read)
 // so the wave (1) gathers the coordinates of ~70 nodes into LDS once, (2)
 // reads everything else from LDS: three dependent latencies per chunk.
 // The global element->node map is not read at all.
@@ -122,12 +122,11 @@ void k_assemble_visit(VisitArgs A)
             __hip_atomic_fetch_add(&sF[lane & 3][n0 * 3 + i], -rv.s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (DOK) {
-          const int rowoff = sRow[n0] * 9;               // row node first: n0 is the row, chunk-local
 #pragma unroll
           for (int k = 1; k < 4; ++k) {                  // the diagonal block comes from the row sum
             double blk[9];
             block_row(rv, s.g[k], blk);
-            double *dst = sKt + rowoff + (int)((sl >> (8 * k)) & 255u) * 9;
+            double *dst = sKt + (int)((sl >> (8 * k)) & 255u) * 9;    // tile position of block (row n0, column k)
             if (DBG && A.dbg & 1) dst = sKt + lane * 9;
 #pragma unroll
             for (int q = 0; q < 9; ++q)
@@ -325,12 +324,11 @@ void k_assemble_run(VisitArgs A, int run_len)
               __hip_atomic_fetch_add(&sF[lane & 1][n0 * 3 + i], -rv.s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
           if (DOK) {
-            const int rowoff = sRow[n0] * 9;
 #pragma unroll
             for (int k = 1; k < 4; ++k) {
               double blk[9];
               block_row(rv, s.g[k], blk);
-              double *dst = sKt + rowoff + (int)((sl >> (8 * k)) & 255u) * 9;
+              double *dst = sKt + (int)((sl >> (8 * k)) & 255u) * 9;
               if (DBG && (A.dbg & 1)) dst = sKt + lane * 9;
 #pragma unroll
               for (int q = 0; q < 9; ++q)

@@ -367,7 +367,8 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
         for (int x = 0; x < 4; ++x) for (int y = x + 1; y < 4; ++y) inv += perm[x] > perm[y];
         uint32_t ids = 0, sl = (uint32_t)(inv & 1);
         for (int k = 0; k < 4; ++k) ids |= (uint32_t)lid(conn[(size_t)e * 4 + perm[k]]) << (8 * k);   // row node first
-        for (int k = 1; k < 4; ++k) sl |= (uint32_t)v.slot[v.order[k - 1]] << (8 * k);
+        // tile position of the block (row start + column slot): the kernel needs no row table in its passes
+        for (int k = 1; k < 4; ++k) sl |= (uint32_t)(hp.rowptr[r0 + v.row] - b0 + v.slot[v.order[k - 1]]) << (8 * k);
         out.vrec[(size_t)(p0 + i) * 2] = ids;
         out.vrec[(size_t)(p0 + i) * 2 + 1] = sl;
       }
