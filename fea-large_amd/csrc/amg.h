@@ -50,6 +50,7 @@ struct AmgHierarchy {
                                          // 10M-tet block, PCG to 1e-14: V-cycle 274 iterations (over 1.5), W-cycle below the
                                          // finest level 150, W-cycle on every level 94 (339 ms against 1 704 ms block-Jacobi)
   bool numeric_valid = false;
+  unsigned long long num_epoch = 0; bool num_bc = false;     // the matrix the numeric part was built for
   int row0 = 0, row1 = 0;                // rows of level 0 this hierarchy covers (the rank's own)
   double *d_z = nullptr;                 // level-0 output of the V-cycle
   double *d_pw = nullptr;                // scratch for the power iteration

@@ -423,7 +423,11 @@ int amg_prepare(feahip_ctx *c)
   AmgHierarchy *h = H(c);
   if (h && (h->row0 != c->row0 || h->row1 != c->row1)) { amg_destroy(c); h = nullptr; }     // the shard changed
   if (!h && (rc = amg_create(c))) return rc;
-  return amg_numeric(c);
+  h = H(c);
+  if (h->numeric_valid && h->num_epoch == c->k_epoch && h->num_bc == c->k_bc) return FEAHIP_OK;   // same K as last time
+  if ((rc = amg_numeric(c))) return rc;
+  h->num_epoch = c->k_epoch; h->num_bc = c->k_bc;
+  return FEAHIP_OK;
 }
 
 // z = M^-1 r on the rank's rows (z stays zero elsewhere); q is used as scratch

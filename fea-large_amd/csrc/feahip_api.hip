@@ -284,9 +284,9 @@ extern "C" int feahip_update_state(feahip_ctx *c, int *n_bad)
   return FEAHIP_OK;
 }
 
-extern "C" int feahip_create_stiffness(feahip_ctx *c) { CTX_GUARD(c); return launch_assemble(c, true, false); }
+extern "C" int feahip_create_stiffness(feahip_ctx *c) { CTX_GUARD(c); ++c->k_epoch; c->k_bc = false; return launch_assemble(c, true, false); }
 extern "C" int feahip_create_residual_forces(feahip_ctx *c) { CTX_GUARD(c); return launch_assemble(c, false, true); }
-extern "C" int feahip_create_stiffness_and_residual(feahip_ctx *c) { CTX_GUARD(c); return launch_assemble(c, true, true); }
+extern "C" int feahip_create_stiffness_and_residual(feahip_ctx *c) { CTX_GUARD(c); ++c->k_epoch; c->k_bc = false; return launch_assemble(c, true, true); }
 
 extern "C" int feahip_stash_stiffness(feahip_ctx *c)
 {
@@ -295,6 +295,7 @@ extern "C" int feahip_stash_stiffness(feahip_ctx *c)
   if (!c->d_Kstash) FEA_HIP_CHECK(c, hipMalloc((void **)&c->d_Kstash, bytes ? bytes : 8));
   FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_Kstash, c->d_K, bytes, hipMemcpyDeviceToDevice, c->stream));
   c->have_stash = true;
+  c->stash_epoch = c->k_epoch;
   return FEAHIP_OK;
 }
 
@@ -304,10 +305,11 @@ extern "C" int feahip_restore_stiffness(feahip_ctx *c)
   if (!c->have_stash) { c->err = "restore_stiffness before stash_stiffness"; return FEAHIP_ESTATE; }
   FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_K, c->d_Kstash, sizeof(double) * 9 * (size_t)c->nnzb,
                                   hipMemcpyDeviceToDevice, c->stream));
+  c->k_epoch = c->stash_epoch; c->k_bc = false;
   return FEAHIP_OK;
 }
 
-extern "C" int feahip_apply_prescribed_bc(feahip_ctx *c, double lambda) { CTX_GUARD(c); return launch_apply_bc(c, lambda); }
+extern "C" int feahip_apply_prescribed_bc(feahip_ctx *c, double lambda) { CTX_GUARD(c); c->k_bc = true; return launch_apply_bc(c, lambda); }
 
 extern "C" int feahip_solve_slae(feahip_ctx *c, int type, double tol, int max_iter, int *iters, double *resid)
 {

@@ -115,6 +115,11 @@ struct feahip_ctx {
   int last_bad = 0;
 
   // preconditioner of PCG_ILU / CHOLESKY solves: 0 = 3x3 block-Jacobi, 1 = aggregation multigrid (amg.h)
+  // which matrix d_K holds: bumped by every stiffness assembly, copied by stash / restore; k_bc = prescribed-dof
+  // masking applied since.  Only used to skip numeric re-setup of the multigrid hierarchy for an unchanged K
+  // (modified Newton restores the same matrix every iteration); a stale hierarchy would cost iterations, not accuracy.
+  unsigned long long k_epoch = 0, stash_epoch = 0;
+  bool k_bc = false;
   // golden-section line search along the Newton step: iterations (0 = off, the reference's solve())
   int linesearch_max = 0;
   int precond = 0;
