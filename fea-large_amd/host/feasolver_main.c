@@ -3,6 +3,11 @@
  * (fea_solver.c:64-128, 324-333) on top of the HIP path.  Loads the deck,
  * runs the load-increment / Newton loop through the C ABI, writes
  * "<base>.msh" like initial_data_load + solve() do.
+ *
+ * One option the reference does not have, after the deck name:
+ *   --multigrid   PCG_ILU / CHOLESKY solves use the aggregation-multigrid
+ *                 preconditioner (feahip_set_preconditioner); ignored with a
+ *                 note when the mesh is too small to coarsen.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -30,6 +35,8 @@ int main(int argc, char **argv)
     fea_deck_free(&deck);
     return 1;
   }
+  if (argc > 2 && strcmp(argv[2], "--multigrid") == 0 && feahip_set_preconditioner(ctx, 1))
+    printf("multigrid preconditioner not used: %s\n", feahip_last_error(ctx));
   steps = (fea_step_snapshot *)calloc((size_t)(deck.load_increments_count > 0 ? deck.load_increments_count : 1), sizeof *steps);
   done = fea_solve_with_snapshots(&deck, ctx, stdout, steps, deck.load_increments_count);
   if (done < 0) {

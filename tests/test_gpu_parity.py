@@ -505,3 +505,7 @@ def test_feasolver_hip_command_line(decks_dir, tmp_path):
     last = [i for i, l in enumerate(msh) if l == "$NodeData"][-1]
     row = msh[last + 9 + top].split()
     assert int(row[0]) == top + 1 and float(row[2]) == pytest.approx(0.1, abs=1e-6)
+    # the one extra option: on this 737-node deck the multigrid is refused with a note and the run is the same
+    res2 = subprocess.run([exe, str(deckfile), "--multigrid"], capture_output=True, text=True, timeout=300)
+    assert res2.returncode == 0 and "multigrid preconditioner not used" in res2.stdout
+    assert res2.stdout.count("Newton iteration") == 25
