@@ -181,6 +181,7 @@ void build_host_patches(int N, int E, const int *conn, const HostPattern &hp, Ho
 #define FEA_VISIT_MAX_NODES 64
 #define FEA_VISIT_MAX_VISITS 128
 #define FEA_ACHUNK_BLOCKS 80
+#define FEA_ACHUNK_ROWS 8              // rows of a staged-assembly chunk (sizes its f tile: 16 workgroups per CU fit)
 #define FEA_SUPER_CHUNKS 8            // a "super" = 8 SpMV chunks; both partitions break at supers; unit of the row shard
 struct VisitDesc {                   // 32 bytes, one per chunk
   int r0, r1, b0, nb;

@@ -43,9 +43,9 @@ void k_assemble_visit(VisitArgs A)
 {
   __shared__ double sC[FEA_VISIT_MAX_NODES * 6];       // x, X0 of the chunk's nodes
   __shared__ double sK[DOK ? FEA_ACHUNK_BLOCKS * 9 + 2 : 2];
-  __shared__ double sF[4][FEA_CHUNK_ROWS * 3 + 3];        // 4 replicas (a row's visits spread over them), padded off the same banks
-  __shared__ int sRow[FEA_CHUNK_ROWS + 1];             // first block of every row, relative to b0
-  __shared__ int sDiag[FEA_CHUNK_ROWS];
+  __shared__ double sF[4][FEA_ACHUNK_ROWS * 3 + 3];        // 4 replicas (a row's visits spread over them), padded off the same banks
+  __shared__ int sRow[FEA_ACHUNK_ROWS + 1];             // first block of every row, relative to b0
+  __shared__ int sDiag[FEA_ACHUNK_ROWS];
   const int lane = threadIdx.x;
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
   if (DBG && A.dbg & 4) t0 = __builtin_amdgcn_s_memtime();
@@ -84,7 +84,7 @@ void k_assemble_visit(VisitArgs A)
   if (DOK)
     for (int t = lane; t < d.nb * 9; t += 64) sKt[t] = 0.0;
   if (DOF)
-    for (int t = lane; t < 4 * (FEA_CHUNK_ROWS * 3 + 3); t += 64) (&sF[0][0])[t] = 0.0;
+    for (int t = lane; t < 4 * (FEA_ACHUNK_ROWS * 3 + 3); t += 64) (&sF[0][0])[t] = 0.0;
   __syncthreads();
   if (DBG && A.dbg & 4) t1 = __builtin_amdgcn_s_memtime();
 
@@ -233,9 +233,9 @@ void k_assemble_run(VisitArgs A, int run_len)
   // lane-linear as global_load_lds writes it: (x0,x1) (x2,-) (X0,X1) (X2,-)
   __shared__ double2 sC[4][FEA_VISIT_MAX_NODES];
   __shared__ double sK[DOK ? FEA_ACHUNK_BLOCKS * 9 + 2 : 2];
-  __shared__ double sF[2][FEA_CHUNK_ROWS * 3 + 3];
-  __shared__ int sRow[FEA_CHUNK_ROWS + 1];
-  __shared__ int sDiag[FEA_CHUNK_ROWS];
+  __shared__ double sF[2][FEA_ACHUNK_ROWS * 3 + 3];
+  __shared__ int sRow[FEA_ACHUNK_ROWS + 1];
+  __shared__ int sDiag[FEA_ACHUNK_ROWS];
   const int lane = threadIdx.x;
   const int nruns = (A.nchunks + run_len - 1) / run_len;
   const int per = ((int)gridDim.x + 7) >> 3;
@@ -266,7 +266,7 @@ void k_assemble_run(VisitArgs A, int run_len)
   if (DOK)
     for (int t = lane; t < FEA_ACHUNK_BLOCKS * 9 + 2; t += 64) sK[t] = 0.0;
   if (DOF)
-    for (int t = lane; t < 2 * (FEA_CHUNK_ROWS * 3 + 3); t += 64) (&sF[0][0])[t] = 0.0;
+    for (int t = lane; t < 2 * (FEA_ACHUNK_ROWS * 3 + 3); t += 64) (&sF[0][0])[t] = 0.0;
   FEA_VMEM_DRAIN();
   FEA_LDS_ORDER();
 
@@ -283,7 +283,7 @@ void k_assemble_run(VisitArgs A, int run_len)
     const int cn = more ? chunk + 1 : chunk;
     const int vn1 = A.vnode[(size_t)cn * FEA_VISIT_MAX_NODES + lane];
     // its rows start where this chunk's end (d.r1): row pointers and diagonal positions, raw
-    const int rrow = min(d.r1 + min(lane, FEA_CHUNK_ROWS), A.nrows_total);
+    const int rrow = min(d.r1 + min(lane, FEA_ACHUNK_ROWS), A.nrows_total);
     const int rp = A.rowptr[rrow];
     const int dg = A.diag[min(rrow, A.nrows_total - 1)];
     // (descriptor: an explicit scalar load -- after the first store the compiler

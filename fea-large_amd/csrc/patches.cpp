@@ -173,7 +173,7 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
       const int nown = r1 - r0;
       d.nnode = nown + (int)halo.size();
       if (d.nnode > FEA_VISIT_MAX_NODES || d.nvisit > FEA_VISIT_MAX_VISITS || d.nb > FEA_ACHUNK_BLOCKS ||
-          nown > FEA_CHUNK_ROWS) { bad[p] = 1; continue; }
+          nown > FEA_ACHUNK_ROWS) { bad[p] = 1; continue; }
       int *vn = out.vnode.data() + (size_t)p * FEA_VISIT_MAX_NODES;
       for (int r = r0; r < r1; ++r) vn[r - r0] = r;
       std::copy(halo.begin(), halo.end(), vn + nown);

@@ -130,7 +130,7 @@ int build_host_pattern(int N, int E, int npe, const int *conn, HostPattern &hp,
       while (r0 < rb) {
         int r = r0, nblk = 0, nvis = 0, nnod = 0;
         ++serial;
-        for (; r < rb && r - r0 < FEA_CHUNK_ROWS; ++r) {
+        for (; r < rb && r - r0 < FEA_ACHUNK_ROWS; ++r) {
           const int len = hp.rowptr[r + 1] - hp.rowptr[r], vis = hp.incptr[r + 1] - hp.incptr[r];
           // nodes this row would add
           int add = 0;
