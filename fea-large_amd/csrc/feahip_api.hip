@@ -125,6 +125,7 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
       if ((rc = dev_upload(c, &c->d_vnode, hv.vnode.data(), hv.vnode.size()))) return rc;
       if ((rc = dev_upload(c, &c->d_vrec, hv.vrec.data(), hv.vrec.size()))) return rc;
       c->have_visits = true;
+      c->nvisit_records = (int)(hv.vrec.size() / 2);
       c->visit_bytes = (long long)(hv.desc.size() * sizeof(VisitDesc) + hv.vnode.size() * 4 + hv.vrec.size() * 4);
       HostPairs pr;
       build_host_pairs(elements, hp, hv, pr);

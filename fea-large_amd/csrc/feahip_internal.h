@@ -83,6 +83,7 @@ struct feahip_ctx {
   int *d_vnode = nullptr;
   uint32_t *d_vrec = nullptr;
   long long visit_bytes = 0;
+  int nvisit_records = 0;      // length of vrec in records (whole passes per chunk)
   bool have_quad = false;
   struct QuadDesc *d_qdesc = nullptr;
   uint32_t *d_qelem = nullptr, *d_qpair = nullptr;
@@ -186,7 +187,7 @@ void build_host_patches(int N, int E, const int *conn, const HostPattern &hp, Ho
 struct VisitDesc {                   // 32 bytes, one per chunk
   int r0, r1, b0, nb;
   int node_off, nnode;               // into vnode
-  int visit_off, nvisit;             // into vrec (same numbering as the inc array)
+  int visit_off, nvisit;             // into vrec: first record, records (a multiple of 64: whole passes)
 };
 struct HostVisits {
   std::vector<VisitDesc> desc;

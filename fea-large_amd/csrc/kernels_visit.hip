@@ -92,7 +92,7 @@ void k_assemble_visit(VisitArgs A)
     // record of the next pass, in flight while this one computes
     uint2 nxt = make_uint2(0, 0);
     if (p + 64 < d.nvisit) nxt = A.vrec[d.visit_off + p + 64];
-    if (p < d.nvisit) {
+    if (p < d.nvisit && rec.y != 0xFFFFFFFFu) {           // 0xFFFFFFFF: idle lane of the schedule
       const unsigned ids = rec.x, sl = rec.y;
       const int n0 = ids & 255u, n1 = (ids >> 8) & 255u, n2 = (ids >> 16) & 255u, n3 = ids >> 24;
       const int nd[4] = {n0, n1, n2, n3};
@@ -296,7 +296,7 @@ void k_assemble_run(VisitArgs A, int run_len)
       // (the visits of consecutive chunks are consecutive in vrec)
       const int gi = d.visit_off + min(p + 64, d.nvisit) + lane;
       const uint2 nxt = A.vrec[min(gi, A.nvisits - 1)];
-      if (p + lane < d.nvisit) {
+      if (p + lane < d.nvisit && rec.y != 0xFFFFFFFFu) {
         const unsigned ids = rec.x, sl = rec.y;
         const int n0 = ids & 255u, n1 = (ids >> 8) & 255u, n2 = (ids >> 16) & 255u, n3 = ids >> 24;
         const int nd[4] = {n0, n1, n2, n3};
@@ -423,7 +423,7 @@ int launch_assemble_visit(feahip_ctx *c, bool doK, bool doF, bool pipelined)
   A.chunk0 = c->achunk0; A.nchunks = c->nachunks_local; A.model = c->model;
   A.lambda = c->lambda; A.mu = c->mu; A.tab = c->d_table; A.desc = c->d_vdesc; A.vnode = c->d_vnode;
   A.vrec = reinterpret_cast<const uint2 *>(c->d_vrec); A.X0 = c->d_X0; A.x = c->d_x;
-  A.rowptr = c->d_rowptr; A.diag = c->d_diag; A.nvisits = c->E * 4; A.nrows_total = c->N; A.K = c->d_K; A.f = c->d_f; A.bad = c->d_flag + 1;
+  A.rowptr = c->d_rowptr; A.diag = c->d_diag; A.nvisits = c->nvisit_records; A.nrows_total = c->N; A.K = c->d_K; A.f = c->d_f; A.bad = c->d_flag + 1;
   { const char *e = getenv("FEAHIP_DBG"); A.dbg = e ? atoi(e) : 0; }
   static unsigned long long *d_stamps = nullptr;
   if ((A.dbg & 4) && !d_stamps) (void)hipMalloc((void **)&d_stamps, sizeof(unsigned long long) * 8 * (size_t)c->nachunks);

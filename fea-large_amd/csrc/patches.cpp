@@ -143,7 +143,17 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
   if (hp.achunk.size() < 2) return;
   const int np = (int)hp.achunk.size() - 1;
   out.desc.resize((size_t)np);
-  out.vrec.assign((size_t)E * 4 * 2, 0);
+  // Records are laid out in whole passes of 64 lanes per chunk: the lanes a chunk leaves idle (its visit count
+  // is rarely a multiple of 64) are spread over the 16-lane LDS groups instead of trailing the last pass, which
+  // gives the bank-aware schedule below room (a group of 14-15 visits needs 14-15 distinct residues out of 16,
+  // not 16 out of 16).  Idle lanes carry the null record (slots = 0xFFFFFFFF).
+  std::vector<long long> voff((size_t)np + 1, 0);
+  for (int p = 0; p < np; ++p) {
+    const int n = hp.incptr[hp.achunk[p + 1]] - hp.incptr[hp.achunk[p]];
+    voff[p + 1] = voff[p] + 64LL * ((n + 63) / 64);
+  }
+  if (voff[np] > 0x7FFFFFFFLL) return;
+  out.vrec.assign((size_t)voff[np] * 2, 0xFFFFFFFFu);
   out.vnode.assign((size_t)np * FEA_VISIT_MAX_NODES, 0);
   std::vector<char> bad((size_t)np, 0);
   const char *ord = getenv("FEAHIP_VISIT_ORDER");
@@ -158,7 +168,7 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
       const int b0 = hp.rowptr[r0];
       VisitDesc &d = out.desc[p];
       d.r0 = r0; d.r1 = r1; d.b0 = b0; d.nb = hp.rowptr[r1] - b0;
-      d.node_off = p * FEA_VISIT_MAX_NODES; d.visit_off = p0; d.nvisit = p1 - p0;
+      d.node_off = p * FEA_VISIT_MAX_NODES; d.visit_off = (int)voff[p]; d.nvisit = p1 - p0;
       // owned rows first (chunk-local id = row - r0), then the other nodes ascending
       halo.clear();
       for (int q = p0; q < p1; ++q) {
@@ -214,7 +224,8 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
         // blocks of one step are distinct mod 16: greedy, least collisions
         // first, then a pass of pairwise swaps for the visits still colliding.
         const int n = (int)vs.size();
-        const int ngroups = (n + 15) / 16;
+        const int ngroups = 4 * ((n + 63) / 64);                       // every 16-lane group of the chunk's passes
+        const int gcap = (n + ngroups - 1) / ngroups;                  // visits per group, evenly (<= 16)
         // pos = tile position of the block; two lanes on one block (same address) serialise
         // harder than two blocks on one bank, so that costs 4 collisions
         std::vector<int> pos((size_t)n * 3);
@@ -224,7 +235,7 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
         auto CA = [&](int g, int st, int ps) -> uint8_t & { return cnta[((size_t)g * 3 + st) * 256 + ps]; };
         std::vector<int> gsize((size_t)ngroups, 0), gof((size_t)n, -1), pof((size_t)n, 0);
         auto C = [&](int g, int st, int res) -> uint8_t & { return cnt[((size_t)g * 3 + st) * 16 + res]; };
-        auto cap = [&](int g) { return std::min(16, n - 16 * g); };
+        auto cap = [&](int) { return gcap; };
         auto cost_in = [&](int i, int g, int pi) {
           int cst = 0;
           for (int st = 0; st < 3; ++st) {
@@ -359,6 +370,7 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
           vs.swap(tmp2);
         }
       }
+      std::vector<int> fill((size_t)4 * ((vs.size() + 63) / 64), 0);
       for (int i = 0; i < (int)vs.size(); ++i) {
         const V &v = vs[i];
         const int e = (int)(v.w & 0x0FFFFFFFu), la = (int)(v.w >> 28);
@@ -369,9 +381,11 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
         for (int k = 0; k < 4; ++k) ids |= (uint32_t)lid(conn[(size_t)e * 4 + perm[k]]) << (8 * k);   // row node first
         // tile position of the block (row start + column slot): the kernel needs no row table in its passes
         for (int k = 1; k < 4; ++k) sl |= (uint32_t)(hp.rowptr[r0 + v.row] - b0 + v.slot[v.order[k - 1]]) << (8 * k);
-        out.vrec[(size_t)(p0 + i) * 2] = ids;
-        out.vrec[(size_t)(p0 + i) * 2 + 1] = sl;
+        const int at = bank_aware ? 16 * v.round + fill[(size_t)v.round]++ : i;   // its lane: inside its group, or packed
+        out.vrec[((size_t)d.visit_off + at) * 2] = ids;
+        out.vrec[((size_t)d.visit_off + at) * 2 + 1] = sl;
       }
+      d.nvisit = 64 * ((d.nvisit + 63) / 64);            // the kernel walks whole passes; idle lanes hold the null record
     }
   });
   for (int p = 0; p < np; ++p)
