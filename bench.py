@@ -55,13 +55,14 @@ def pmc_traffic(args, world):
         return None
 
 
-def cpu_baseline(n_sample, seconds_cap=40.0):
+def cpu_baseline(n_sample, quadratic=False, model=None):
     """The oracle (CPU restatement of the reference loops, 1 thread) timed on
     a bounded sample of the same workload: a smaller Kuhn block of the same
     bar in the same deformed state."""
     import mesh
     from oracle_binding import OracleSolver
-    deck = mesh.bar_deck(n=n_sample)
+    kw = {} if model is None else {"model": model}
+    deck = mesh.bar_deck(n=n_sample, quadratic=quadratic, **kw)
     o = OracleSolver(deck)
     o.set_nodes(mesh.deformed_state(deck.nodes))
     t0 = time.perf_counter()
@@ -71,7 +72,7 @@ def cpu_baseline(n_sample, seconds_cap=40.0):
     dt = time.perf_counter() - t0
     E = len(deck.elements)
     return {"value": E / dt, "unit": "elements/s", "cores": 1, "kind": "port",
-            "sample": f"{E} TET4 of the same bar ({n_sample}x{6 * n_sample}x{n_sample} cubes), "
+            "sample": f"{E} {'TET10/5GP' if quadratic else 'TET4'} of the same bar ({n_sample}x{6 * n_sample}x{n_sample} cubes), "
                       f"state+stiffness+residual, {dt:.1f} s, oracle/fea_oracle.c -O2 -ffp-contract=off"}
 
 
@@ -245,7 +246,7 @@ def main():
             extras["solve_leg"] = f"failed: {e}"
     watchdog.cancel()
     if rank == 0 and args.cpu_sample > 0 and world == 1:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.quadratic, model)
     emit()
     solver.close()
     if world > 1:
