@@ -84,9 +84,12 @@ def main():
     ap.add_argument("--n", type=int, default=66, help="block of n x 6n x n cubes (66 = 10M tets, 31 = 1M)")
     ap.add_argument("--quadratic", action="store_true", help="TET10 / 5 Gauss points instead of TET4 / 1")
     ap.add_argument("--model", default="neohookean", choices=["neohookean", "a5"])
-    ap.add_argument("--cpu-sample", type=int, default=20, help="n of the CPU-baseline sample block (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=None,
+                    help="n of the CPU-baseline sample block (0 = skip; default: ~10 s of single-core work, 48 for TET4, 14 for TET10)")
     ap.add_argument("--no-newton", action="store_true", help="skip the single full Newton iteration")
     args = ap.parse_args()
+    if args.cpu_sample is None:
+        args.cpu_sample = 14 if args.quadratic else 48
 
     import torch
     import feahip
