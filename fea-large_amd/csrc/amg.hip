@@ -404,7 +404,9 @@ static void amg_cycle(feahip_ctx *c, int l, const double *r, double *x, double *
     enq_spmv_arrays(c->stream, R.ch0, R.nch, L.chunk, L.rowptr, L.colidx, L.K, x, y);
     hipLaunchKernelGGL(k_restrict, G256((C.N / 2) * 16), C.N / 2, L.aptr, L.anodes, L.type, L.doff, r, y, mask, C.r);
     amg_cycle(c, l + 1, C.r, C.x, C.y);
-    hipLaunchKernelGGL(k_prolong, G256(L.N), L.N, L.agg, L.type, L.doff, C.x, mask, h->over, x);
+    // over-correction only where the correction is applied twice: (I - aE)^2 >= 0 for any a <= 2, while a single
+    // over-corrected step can flip the sign of the preconditioner on part of the spectrum (seen: 6 492 iterations)
+    hipLaunchKernelGGL(k_prolong, G256(L.N), L.N, L.agg, L.type, L.doff, C.x, mask, gamma >= 2 ? h->over : fmin(h->over, 1.0), x);
   }
   enq_spmv_arrays(c->stream, R.ch0, R.nch, L.chunk, L.rowptr, L.colidx, L.K, x, y);
   hipLaunchKernelGGL(k_smooth_next, GROWS(R), R.a0, R.a1, L.omega, L.minv, r, y, x);
