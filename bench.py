@@ -76,6 +76,46 @@ def cpu_baseline(n_sample, quadratic=False, model=None):
                       f"state+stiffness+residual, {dt:.1f} s, oracle/fea_oracle.c -O2 -ffp-contract=off"}
 
 
+_WORKER = r"""
+import json, sys, time
+sys.path[:0] = [sys.argv[1], sys.argv[2]]
+import mesh
+from oracle_binding import OracleSolver
+n, quadratic, model, t_go = int(sys.argv[3]), sys.argv[4] == "1", int(sys.argv[5]), float(sys.argv[6])
+deck = mesh.bar_deck(n=n, quadratic=quadratic, model=model)
+o = OracleSolver(deck)
+o.set_nodes(mesh.deformed_state(deck.nodes))
+while time.time() < t_go:            # all copies start their timed region together
+    time.sleep(0.01)
+t0 = time.perf_counter()
+o.update_state(); o.create_stiffness(); o.create_residual_forces()
+print(json.dumps({"E": len(deck.elements), "dt": time.perf_counter() - t0, "late": time.time() - t_go}))
+"""
+
+
+def cpu_baseline_all_cores(n_sample, quadratic, model, cores):
+    """The same single-threaded oracle, one independent copy of the sample block per host core, all timed
+    together: the reference is single-threaded by construction, so this is what the box's cores
+    can do with it -- independent problems side by side.  Separate processes, started before the GPU is touched."""
+    import subprocess
+    t_go = time.time() + (14.0 if not quadratic else 8.0) + 0.12 * n_sample
+    args = [sys.executable, "-c", _WORKER, os.path.join(ROOT, "fea-large_amd"), os.path.join(ROOT, "tests"),
+            str(n_sample), "1" if quadratic else "0", str(model), repr(t_go)]
+    procs = [subprocess.Popen(args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(cores)]
+    outs = []
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=300)
+            outs.append(json.loads(o.strip().splitlines()[-1]))
+        except Exception:                           # noqa: BLE001
+            pr.kill()
+    if not outs or max(r["late"] - r["dt"] for r in outs) > 0.5:       # a copy missed the common start
+        return None
+    E = outs[0]["E"]
+    return {"value": sum(r["E"] / r["dt"] for r in outs), "cores": len(outs),
+            "slowest_copy_s": max(r["dt"] for r in outs), "elements_per_copy": E}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,17 +127,25 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=None,
                     help="n of the CPU-baseline sample block (0 = skip; default: ~10 s of single-core work, 48 for TET4, 14 for TET10)")
     ap.add_argument("--no-newton", action="store_true", help="skip the single full Newton iteration")
+    ap.add_argument("--cpu-single-only", action="store_true", help="skip the one-oracle-copy-per-core CPU baseline")
     args = ap.parse_args()
     if args.cpu_sample is None:
         args.cpu_sample = 14 if args.quadratic else 48
 
-    import torch
-    import feahip
-    import mesh
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    import feahip
+    import mesh
+    model = feahip.MODEL_COMPRESSIBLE_NEOHOOKEAN if args.model == "neohookean" else feahip.MODEL_A5
+    cpu_all = None
+    if world == 1 and args.cpu_sample > 0 and not args.cpu_single_only:
+        # before anything touches the GPU: child processes, one oracle copy per host core (at most 16)
+        try:
+            cpu_all = cpu_baseline_all_cores(args.cpu_sample, args.quadratic, model, min(16, os.cpu_count() or 1))
+        except Exception as e:                      # noqa: BLE001
+            print(f"all-cores CPU baseline skipped: {e}", file=sys.stderr)
+    import torch
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
@@ -115,7 +163,6 @@ def main():
         if world > 1:
             dist.barrier()
 
-    model = feahip.MODEL_COMPRESSIBLE_NEOHOOKEAN if args.model == "neohookean" else feahip.MODEL_A5
     t_setup = time.perf_counter()
     deck = mesh.bar_deck(n=args.n, quadratic=args.quadratic, recipe="clamped", model=model,
                          solver_type=feahip.PCG_ILU, solver_tolerance=1e-14, solver_max_iter=20000)
@@ -250,6 +297,10 @@ def main():
     watchdog.cancel()
     if rank == 0 and args.cpu_sample > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.quadratic, model)
+        if cpu_all is not None:
+            cpu_all["unit"] = "elements/s"
+            cpu_all["note"] = "independent copies of the same sample, one single-threaded oracle per core, timed together"
+            out["cpu_baseline"]["all_cores"] = cpu_all
     emit()
     solver.close()
     if world > 1:
