@@ -119,8 +119,8 @@ def cpu_baseline_all_cores(n_sample, quadratic, model, cores):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=66, help="block of n x 6n x n cubes (66 = 10M tets, 31 = 1M)")
     ap.add_argument("--quadratic", action="store_true", help="TET10 / 5 Gauss points instead of TET4 / 1")
     ap.add_argument("--model", default="neohookean", choices=["neohookean", "a5"])
@@ -177,6 +177,13 @@ def main():
     t_setup = time.perf_counter() - t_setup
 
     E_total, N, nnz = sz["E"], sz["N"], sz["nnzb"] * 9
+    # The device needs ~25 back-to-back launches (~30 ms of load) to reach its sustained clocks: the rocprofv3 trace
+    # of this program shows the same kernel on the same data going from 1.25 to 1.01 ms over its first 25 launches
+    # (profiles/r01_l_*).  A Newton loop keeps the device busy for seconds, so the sustained rate is the
+    # one to report: a fixed, untimed ramp precedes the contract's W warm-up steps and K timed steps.
+    RAMP = 30
+    for _ in range(RAMP):
+        solver.create_stiffness_and_residual()
     for _ in range(args.warmup):
         solver.create_stiffness_and_residual()
     solver.sync(); torch.cuda.synchronize(); barrier()
@@ -215,7 +222,7 @@ def main():
         "config": {"workload": f"{E_total} {'TET10/5GP' if args.quadratic else 'TET4/1GP'} {args.model} block "
                                f"({args.n}x{6 * args.n}x{args.n} Kuhn cubes on the 1x6x1 bar), "
                                f"stiffness+residual assembly, deformed state k1=1.1",
-                   "elements": E_total, "nodes": N, "scalar_nnz": nnz,
+                   "elements": E_total, "nodes": N, "scalar_nnz": nnz, "clock_ramp_launches_before_warmup": RAMP,
                    "sharding": f"block rows in {world} slab(s) across y, ghost elements recomputed, "
                                f"no collective in assembly"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
