@@ -82,7 +82,8 @@ void k_assemble_visit(VisitArgs A)
     o[0] = a0.x; o[1] = a0.y; o[2] = a1.x; o[3] = c0.x; o[4] = c0.y; o[5] = c1.x;
   }
   if (DOK)
-    for (int t = lane; t < d.nb * 9; t += 64) sKt[t] = 0.0;
+    for (int t = lane; 2 * t < d.nb * 9 + odd; t += 64)              // 16-byte stores from the aligned base of the tile
+      reinterpret_cast<double2 *>(sK)[t] = make_double2(0.0, 0.0);
   if (DOF)
     for (int t = lane; t < 4 * (FEA_ACHUNK_ROWS * 3 + 3); t += 64) (&sF[0][0])[t] = 0.0;
   __syncthreads();
