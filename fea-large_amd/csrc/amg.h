@@ -12,13 +12,15 @@
 // block to the smoother: 335 iterations on the 1M-tet block against 1266 for
 // block-Jacobi.)  Coarse matrices are Galerkin products P' K P, with the 3x3
 // blocks of P either I, 0 or the cross-product matrix of the offset from the
-// centroid.  Everything that depends
-// on topology only -- aggregates, coarse patterns, which fine blocks sum into
-// which coarse block -- is built once on the host; the numeric part (sums,
+// centroid.  Everything that depends on topology and geometry only --
+// aggregates, centroids, coarse patterns, which fine blocks enter which coarse
+// block -- is built once on the host; the numeric part (Galerkin products,
 // block-diagonal inverses, damping) is redone on the device whenever K
-// changed.  V(1,1) cycle with damped block-Jacobi smoothing, a fixed number
-// of sweeps on the coarsest level: a fixed symmetric positive definite
-// operator, as CG requires.
+// changed.  W-cycle (two coarse corrections per level, over-corrected by 2)
+// with damped block-Jacobi smoothing before and after, a fixed number of
+// sweeps on the coarsest level: a fixed symmetric positive definite operator,
+// as CG requires.  A rank of a sharded solve builds the hierarchy of its own
+// diagonal block (amg_setup.cpp), so the preconditioner needs no communication.
 #pragma once
 #include "feahip_internal.h"
 
