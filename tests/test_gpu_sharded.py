@@ -115,6 +115,23 @@ def test_sharded_multigrid_preconditioner(n):
     g.close(); a.close()
 
 
+def test_sharded_line_search_equals_single_rank():
+    """The golden-section line search inside the Newton driver on 2 ranks (halo
+    copies of u exchanged once per step, trial configurations on every rank):
+    same iteration count, same <u,f> sequence, same nodes as one rank."""
+    deck = mesh.bar_deck(dims=(3, 24, 3), dy=0.3, load_increments_count=1, max_newton_count=25,
+                         desired_tolerance=1e-16, modified_newton=False)
+    one = feahip.FeaSolver(deck)
+    d1, its1, tol1 = one.solve(solver_type=feahip.CHOLESKY, line_search=4)
+    g = feahip.FeaGroup(deck, 2)
+    g.each("set_line_search", 4)
+    gd, gits, gtol = g.solve(1, 25, False, 1e-16, feahip.CHOLESKY)
+    assert gd == d1 == 1 and list(gits) == list(its1)
+    assert np.abs(gtol - tol1).max() < 1e-9 * np.abs(tol1).max()
+    assert rel(g.gather("nodes") - deck.nodes, one.nodes() - deck.nodes) < 1e-10
+    g.close(); one.close()
+
+
 def test_rccl_single_rank_comm():
     """RCCL transport with one rank (all this box can host): unique id,
     communicator, all-reduce of the CG scalars, empty halo exchange."""
