@@ -26,6 +26,54 @@ static int dev_zeros(feahip_ctx *c, T **dst, size_t n)
   return FEAHIP_OK;
 }
 
+int ensure_generic_maps(feahip_ctx *c)
+{
+  if (c->generic_maps) return FEAHIP_OK;
+  if (!c->h_pat) { c->err = "incidence maps unavailable"; return FEAHIP_ESTATE; }
+  const HostPattern &hp = *c->h_pat;
+  int rc;
+  if ((rc = dev_upload(c, &c->d_incptr, hp.incptr.data(), hp.incptr.size()))) return rc;
+  if ((rc = dev_upload(c, &c->d_inc, hp.inc.data(), hp.inc.size()))) return rc;
+  if (!hp.incslot.empty() && (rc = dev_upload(c, &c->d_incslot, hp.incslot.data(), hp.incslot.size()))) return rc;
+  c->generic_maps = true;
+  return FEAHIP_OK;
+}
+
+int ensure_patches(feahip_ctx *c)
+{
+  if (c->have_patches || !c->h_pat || c->h_conn.empty()) return FEAHIP_OK;
+  HostPatches pt;
+  build_host_patches(c->N, c->E, c->h_conn.data(), *c->h_pat, pt);
+  if (!pt.ok) return FEAHIP_OK;
+  int rc;
+  if ((rc = dev_upload(c, &c->d_pdesc, pt.desc.data(), pt.desc.size()))) return rc;
+  if ((rc = dev_upload(c, &c->d_pnode, pt.pnode.data(), pt.pnode.size()))) return rc;
+  if ((rc = dev_upload(c, &c->d_pelem, pt.pelem.data(), pt.pelem.size()))) return rc;
+  if ((rc = dev_upload(c, &c->d_pent, pt.pent.data(), pt.pent.size()))) return rc;
+  if ((rc = dev_upload(c, &c->d_pbptr, pt.pbptr.data(), pt.pbptr.size()))) return rc;
+  c->have_patches = true;
+  c->patch_bytes = (long long)(pt.desc.size() * sizeof(PatchDesc) + pt.pnode.size() * 4 +
+                               pt.pelem.size() * 2 + pt.pent.size() * 2 + pt.pbptr.size() * 2);
+  return FEAHIP_OK;
+}
+
+int ensure_pairs(feahip_ctx *c)
+{
+  if (c->have_pairs || !c->have_visits || !c->h_pat || c->h_conn.empty()) return FEAHIP_OK;
+  HostVisits hv;                                    // the pairing starts from the visit maps: built again, host only
+  build_host_visits(c->N, c->E, c->h_conn.data(), *c->h_pat, hv);
+  if (!hv.ok) return FEAHIP_OK;
+  HostPairs pr;
+  build_host_pairs(c->h_conn.data(), *c->h_pat, hv, pr);
+  if (!pr.ok) return FEAHIP_OK;
+  int rc;
+  if ((rc = dev_upload(c, &c->d_pairdesc, pr.desc.data(), pr.desc.size()))) return rc;
+  if ((rc = dev_upload(c, &c->d_prec, pr.prec.data(), pr.prec.size()))) return rc;
+  c->have_pairs = true;
+  c->pair_bytes = (long long)(pr.desc.size() * sizeof(VisitDesc) + hv.vnode.size() * 4 + pr.prec.size() * 4);
+  return FEAHIP_OK;
+}
+
 static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int npe, int gauss_count,
                        const double *gauss_weights, const double *dforms, const int *elements,
                        const double *nodes0, int model, const double *model_params,
@@ -70,7 +118,8 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
   if ((rc = dev_upload(c, &c->d_table, &c->table, 1))) return rc;
 
   // pattern + incidence maps (host, once)
-  HostPattern hp;
+  c->h_pat = new HostPattern();
+  HostPattern &hp = *c->h_pat;
   if ((rc = build_host_pattern(n_nodes, n_elems, npe, elements, hp, c->err))) return rc;
   c->nnzb = (int)hp.colidx.size();
   c->max_rowlen = hp.max_rowlen;
@@ -82,6 +131,7 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
   c->h_chunk = hp.chunk;
   c->row0 = 0; c->row1 = n_nodes;
   c->h_rowptr = hp.rowptr; c->h_colidx = hp.colidx;
+  c->incslot_ok = !hp.incslot.empty();
 
   if ((rc = dev_upload(c, &c->d_conn, elements, (size_t)n_elems * npe))) return rc;
   {
@@ -93,30 +143,11 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
   }
   if ((rc = dev_upload(c, &c->d_rowptr, hp.rowptr.data(), hp.rowptr.size()))) return rc;
   if ((rc = dev_upload(c, &c->d_colidx, hp.colidx.data(), hp.colidx.size()))) return rc;
-  if ((rc = dev_upload(c, &c->d_incptr, hp.incptr.data(), hp.incptr.size()))) return rc;
-  if ((rc = dev_upload(c, &c->d_inc, hp.inc.data(), hp.inc.size()))) return rc;
-  if (!hp.incslot.empty()) {
-    if ((rc = dev_upload(c, &c->d_incslot, hp.incslot.data(), hp.incslot.size()))) return rc;
-  }
   if ((rc = dev_upload(c, &c->d_chunk, hp.chunk.data(), hp.chunk.size()))) return rc;
   if ((rc = dev_upload(c, &c->d_diag, hp.diag.data(), hp.diag.size()))) return rc;
   c->aux_bytes = (long long)(hp.incptr.size() * 4 + hp.inc.size() * 4 + hp.incslot.size() +
                              hp.chunk.size() * 4 + hp.rowptr.size() * 4 + hp.diag.size() * 4);
 
-  if (c->linear_tet && gauss_count == 1) {
-    HostPatches pt;
-    build_host_patches(n_nodes, n_elems, elements, hp, pt);
-    if (pt.ok) {
-      if ((rc = dev_upload(c, &c->d_pdesc, pt.desc.data(), pt.desc.size()))) return rc;
-      if ((rc = dev_upload(c, &c->d_pnode, pt.pnode.data(), pt.pnode.size()))) return rc;
-      if ((rc = dev_upload(c, &c->d_pelem, pt.pelem.data(), pt.pelem.size()))) return rc;
-      if ((rc = dev_upload(c, &c->d_pent, pt.pent.data(), pt.pent.size()))) return rc;
-      if ((rc = dev_upload(c, &c->d_pbptr, pt.pbptr.data(), pt.pbptr.size()))) return rc;
-      c->have_patches = true;
-      c->patch_bytes = (long long)(pt.desc.size() * sizeof(PatchDesc) + pt.pnode.size() * 4 +
-                                   pt.pelem.size() * 2 + pt.pent.size() * 2 + pt.pbptr.size() * 2);
-    }
-  }
   if (c->linear_tet && gauss_count == 1) {
     HostVisits hv;
     build_host_visits(n_nodes, n_elems, elements, hp, hv);
@@ -127,16 +158,12 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
       c->have_visits = true;
       c->nvisit_records = (int)(hv.vrec.size() / 2);
       c->visit_bytes = (long long)(hv.desc.size() * sizeof(VisitDesc) + hv.vnode.size() * 4 + hv.vrec.size() * 4);
-      HostPairs pr;
-      build_host_pairs(elements, hp, hv, pr);
-      if (pr.ok) {
-        if ((rc = dev_upload(c, &c->d_pairdesc, pr.desc.data(), pr.desc.size()))) return rc;
-        if ((rc = dev_upload(c, &c->d_prec, pr.prec.data(), pr.prec.size()))) return rc;
-        c->have_pairs = true;
-        c->pair_bytes = (long long)(pr.desc.size() * sizeof(VisitDesc) + hv.vnode.size() * 4 + pr.prec.size() * 4);
-      }
     }
   }
+  if (c->have_visits) {
+    // the default path is complete; everything else is built on demand from these
+    c->h_conn.assign(elements, elements + (size_t)n_elems * npe);
+  } else if ((rc = ensure_generic_maps(c))) return rc;
   if (npe == 10) {
     HostQuad hq;
     build_host_quad(n_nodes, n_elems, npe, elements, hp, hq);
@@ -149,6 +176,7 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
       c->quad_bytes = (long long)(hq.desc.size() * sizeof(QuadDesc) + hq.qelem.size() * 4 + hq.qpair.size() * 4 + hq.qnode.size() * 4);
     }
   }
+  if (!c->have_visits) { delete c->h_pat; c->h_pat = nullptr; }          // nothing is built later for these meshes
   if ((rc = dev_zeros(c, &c->d_K, (size_t)c->nnzb * 9 + 2))) return rc;   // +2: the SpMV reads aligned 80-byte windows
   if ((rc = dev_zeros(c, &c->d_f, (size_t)c->ndof))) return rc;
   if ((rc = dev_zeros(c, &c->d_u, (size_t)c->ndof))) return rc;
@@ -210,6 +238,7 @@ extern "C" int feahip_create(feahip_ctx **out, int device, int n_nodes, int n_el
 extern "C" void feahip_destroy(feahip_ctx *c)
 {
   if (!c) return;
+  delete c->h_pat; c->h_pat = nullptr;
   void *ptrs[] = {c->d_table, c->d_conn, c->d_X0, c->d_x, c->d_rowptr, c->d_colidx, c->d_K, c->d_Kstash,
                   c->d_incptr, c->d_inc, c->d_incslot, c->d_chunk, c->d_diag, c->d_pdesc, c->d_pnode, c->d_pelem, c->d_pent, c->d_pbptr, c->d_vdesc, c->d_vnode, c->d_vrec, c->d_pairdesc, c->d_prec, c->d_qdesc, c->d_qelem, c->d_qpair, c->d_qnode, c->d_f, c->d_u, c->d_r, c->d_p,
                   c->d_q, c->d_minv, c->d_part, c->d_scal, c->d_flag, c->d_cdof, c->d_cval,

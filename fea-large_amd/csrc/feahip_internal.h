@@ -111,6 +111,13 @@ struct feahip_ctx {
 
   // host copies needed by getters / pattern export
   std::vector<int> h_rowptr, h_colidx;
+  // Linear tets assemble with the staged visit maps; the maps of the other strategies (generic incidence lists,
+  // patches, pairs: ~1.3 GB and ~2 s of host work at 10M tets) are built the first time a strategy asks for them,
+  // from these host copies.
+  std::vector<int> h_conn;
+  struct HostPattern *h_pat = nullptr;
+  bool generic_maps = false;   // incptr / inc / incslot uploaded
+  bool incslot_ok = false;     // the mesh has them (row length <= 255)
   long long aux_bytes = 0;
 
   int last_bad = 0;
@@ -234,6 +241,9 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF);
 int launch_state_export(feahip_ctx *c);
 int launch_apply_bc(feahip_ctx *c, double lambda);
 int launch_update_nodes_bc(feahip_ctx *c, double lambda);
+int ensure_generic_maps(feahip_ctx *c);
+int ensure_patches(feahip_ctx *c);
+int ensure_pairs(feahip_ctx *c);
 int dist_nodes_add_scaled(std::vector<feahip_ctx *> &R, double eta, bool exchange);
 int launch_update_nodes_solution(feahip_ctx *c, const double *d_u);
 int launch_spmv(feahip_ctx *c, const double *d_xv, double *d_yv);

@@ -292,7 +292,7 @@ static void launch_atomic_t(feahip_ctx *c, const AsmArgs &A, bool doK, bool doF)
 int launch_assemble(feahip_ctx *c, bool doK, bool doF)
 {
   AsmArgs A = make_args(c);
-  const bool rowowner_ok = c->d_incslot != nullptr && c->max_rowlen <= FEA_CHUNK_BLOCKS;
+  const bool rowowner_ok = c->incslot_ok && c->max_rowlen <= FEA_CHUNK_BLOCKS;
   int strat = c->strategy;
   // AUTO: row-owner visits, with LDS-staged coordinates where the maps exist (linear tets);
   // PATCH is the bitwise-reproducible variant, slower today
@@ -310,6 +310,7 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
     return launch_assemble_quad(c, doF);
   }
   if (strat == FEAHIP_ASM_PAIRED) {
+    { const int rc = ensure_pairs(c); if (rc) return rc; }
     if (!c->have_pairs) {
       c->err = "paired assembly needs linear tetrahedra whose chunks fit the LDS tiles";
       return FEAHIP_EINVAL;
@@ -327,6 +328,7 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
   }
   if (strat == FEAHIP_ASM_PATCH && !doK) strat = FEAHIP_ASM_ROWOWNER;   // residual alone: visit kernel
   if (strat == FEAHIP_ASM_PATCH) {
+    { const int rc = ensure_patches(c); if (rc) return rc; }
     if (!c->have_patches) {
       c->err = "patch assembly needs linear tetrahedra whose chunks fit the LDS tiles";
       return FEAHIP_EINVAL;
@@ -334,6 +336,8 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
     FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));
     return launch_assemble_patch(c, doF);
   }
+  { const int rc = ensure_generic_maps(c); if (rc) return rc; }     // the generic kernels walk the incidence lists
+  A.incptr = c->d_incptr; A.inc = c->d_inc; A.incslot = c->d_incslot;
   if (strat == FEAHIP_ASM_ROWOWNER && !rowowner_ok) {
     c->err = "row-owner assembly needs block rows of at most " +
              std::to_string(FEA_CHUNK_BLOCKS) + " blocks (mesh has " +
