@@ -187,9 +187,12 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
       int *vn = out.vnode.data() + (size_t)p * FEA_VISIT_MAX_NODES;
       for (int r = r0; r < r1; ++r) vn[r - r0] = r;
       std::copy(halo.begin(), halo.end(), vn + nown);
+      // chunk-local id of a halo node: position in `halo` -> id (identity order unless renumbered below)
+      std::vector<int> halo_id(halo.size());
+      for (size_t h = 0; h < halo.size(); ++h) halo_id[h] = nown + (int)h;
       auto lid = [&](int g) {
         if (g >= r0 && g < r1) return g - r0;
-        return nown + (int)(std::lower_bound(halo.begin(), halo.end(), g) - halo.begin());
+        return halo_id[(size_t)(std::lower_bound(halo.begin(), halo.end(), g) - halo.begin())];
       };
       struct V { uint32_t w; int row; int slot[3]; int node[3]; int round; int order[3]; };
       std::vector<V> vs;
@@ -370,7 +373,54 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
           vs.swap(tmp2);
         }
       }
-      std::vector<int> fill((size_t)4 * ((vs.size() + 63) / 64), 0);
+      std::vector<int> fill((size_t)4 * ((vs.size() + 63) / 64), 0), lane_of(vs.size());
+      for (int i = 0; i < (int)vs.size(); ++i)
+        lane_of[(size_t)i] = bank_aware ? 16 * vs[i].round + fill[(size_t)vs[i].round]++ : i;   // inside its group, or packed
+      if (bank_aware && !halo.empty()) {
+        // Chunk-local ids of the halo nodes against bank conflicts of the coordinate reads.  A lane reads its four
+        // nodes with ds_read_b128 (48-byte records: 16-byte slot = (3 id + part) mod 16, so two distinct nodes of one
+        // read collide iff their ids agree mod 16); the LDS serves such a read in groups of 16 lanes
+        // ({0-3,12-15,20-27}, {4-11,16-19,28-31} of every 32).  Owned rows keep id = row; halo nodes take the free id
+        // (up to 63) whose residue is least used by the nodes they share a (lane group, node position) read with.
+        static const uint8_t grp_of[32] = {0,0,0,0,1,1,1,1,1,1,1,1,0,0,0,0,1,1,1,1,0,0,0,0,0,0,0,0,1,1,1,1};
+        const int nhalf = (int)(fill.size() / 4) * 2, nsets = nhalf * 2 * 4;
+        std::vector<std::vector<int>> members((size_t)nsets);               // global node ids, distinct
+        for (int i = 0; i < (int)vs.size(); ++i) {
+          const V &v = vs[i];
+          const int e = (int)(v.w & 0x0FFFFFFFu), la = (int)(v.w >> 28), ln = lane_of[(size_t)i];
+          const int nd[4] = {la, v.node[v.order[0]], v.node[v.order[1]], v.node[v.order[2]]};
+          for (int k = 0; k < 4; ++k) {
+            auto &m = members[(size_t)(((ln >> 5) * 2 + grp_of[ln & 31]) * 4 + k)];
+            const int g = conn[(size_t)e * 4 + nd[k]];
+            if (std::find(m.begin(), m.end(), g) == m.end()) m.push_back(g);
+          }
+        }
+        std::vector<uint8_t> cnt((size_t)nsets * 16, 0);
+        std::vector<std::vector<int>> sets_of(halo.size());
+        for (int sidx = 0; sidx < nsets; ++sidx)
+          for (int g : members[(size_t)sidx]) {
+            if (g >= r0 && g < r1) cnt[(size_t)sidx * 16 + ((g - r0) & 15)]++;
+            else sets_of[(size_t)(std::lower_bound(halo.begin(), halo.end(), g) - halo.begin())].push_back(sidx);
+          }
+        std::vector<int> byload(halo.size());
+        for (size_t h = 0; h < halo.size(); ++h) byload[h] = (int)h;
+        std::stable_sort(byload.begin(), byload.end(), [&](int a, int b) { return sets_of[(size_t)a].size() > sets_of[(size_t)b].size(); });
+        bool used[FEA_VISIT_MAX_NODES] = {false};
+        int top = nown;
+        for (int h : byload) {
+          int cost[16] = {0};
+          for (int sidx : sets_of[(size_t)h]) for (int r = 0; r < 16; ++r) cost[r] += cnt[(size_t)sidx * 16 + r];
+          int best = -1;
+          for (int idc = nown; idc < FEA_VISIT_MAX_NODES; ++idc)
+            if (!used[idc] && (best < 0 || cost[idc & 15] < cost[best & 15])) best = idc;
+          used[best] = true; halo_id[(size_t)h] = best; top = std::max(top, best + 1);
+          for (int sidx : sets_of[(size_t)h]) cnt[(size_t)sidx * 16 + (best & 15)]++;
+        }
+        // node list in id order; unused ids read an owned row (harmless)
+        for (int idc = nown; idc < top; ++idc) vn[idc] = r0;
+        for (size_t h = 0; h < halo.size(); ++h) vn[halo_id[h]] = halo[h];
+        d.nnode = top;
+      }
       for (int i = 0; i < (int)vs.size(); ++i) {
         const V &v = vs[i];
         const int e = (int)(v.w & 0x0FFFFFFFu), la = (int)(v.w >> 28);
@@ -381,7 +431,7 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
         for (int k = 0; k < 4; ++k) ids |= (uint32_t)lid(conn[(size_t)e * 4 + perm[k]]) << (8 * k);   // row node first
         // tile position of the block (row start + column slot): the kernel needs no row table in its passes
         for (int k = 1; k < 4; ++k) sl |= (uint32_t)(hp.rowptr[r0 + v.row] - b0 + v.slot[v.order[k - 1]]) << (8 * k);
-        const int at = bank_aware ? 16 * v.round + fill[(size_t)v.round]++ : i;   // its lane: inside its group, or packed
+        const int at = lane_of[(size_t)i];
         out.vrec[((size_t)d.visit_off + at) * 2] = ids;
         out.vrec[((size_t)d.visit_off + at) * 2 + 1] = sl;
       }
@@ -418,9 +468,12 @@ void build_host_pairs(const int *conn, const HostPattern &hp, const HostVisits &
       const VisitDesc &d = hv.desc[p];
       const int r0 = d.r0, r1 = d.r1, nown = r1 - r0;
       const int *vn = hv.vnode.data() + (size_t)p * FEA_VISIT_MAX_NODES;
+      std::vector<std::pair<int, int>> byg;                          // (global id, chunk-local id) of the halo nodes
+      for (int k = nown; k < d.nnode; ++k) byg.push_back({vn[k], k});
+      std::sort(byg.begin(), byg.end());
       auto lid = [&](int g) {
         if (g >= r0 && g < r1) return g - r0;
-        return nown + (int)(std::lower_bound(vn + nown, vn + d.nnode, g) - (vn + nown));
+        return std::lower_bound(byg.begin(), byg.end(), std::make_pair(g, 0))->second;
       };
       struct P { int row; int eA, laA, eB, laB; int p, q, r, s; };   // global node ids; eB < 0: single
       std::vector<P> pairs;
