@@ -153,11 +153,19 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X: the hot path has no CPU mode", file=sys.stderr)
         sys.exit(2)
+    # rehearsal of the multi-rank code path on a box with fewer GPUs than ranks (FEAHIP_BENCH_BACKEND=gloo): ranks
+    # share devices and torch.distributed runs over gloo; the driver's runs use one GPU per rank over nccl (= RCCL)
+    backend = os.environ.get("FEAHIP_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -197,7 +205,7 @@ def main():
     solver.sync(); torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = 1e3 * dt / args.steps
