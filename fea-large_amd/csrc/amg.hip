@@ -6,6 +6,8 @@
 // from kernels_solve.hip
 void enq_spmv_arrays(hipStream_t stream, int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx,
                      const double *K, const double *xv, double *yv);
+void enq_spmv_arrays_f32(hipStream_t stream, int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx,
+                         const float *K, const double *xv, double *yv);
 
 // ---------------------------------------------------------------------------
 // kernels
@@ -21,8 +23,9 @@ __device__ __forceinline__ void cross3(const double *d, double a0, double a1, do
 {
   o0 = d[1] * a2 - d[2] * a1; o1 = d[2] * a0 - d[0] * a2; o2 = d[0] * a1 - d[1] * a0;
 }
+template <class TIN, class TOUT>
 __global__ void k_galerkin(int npair, const int *prow, const int *crowptr, const int *cbptr, const int *cblist,
-                           const double *Kf, double *Kc, const int *cbrow, const int *colidx_f, const uint8_t *type_f,
+                           const TIN *Kf, TOUT *Kc, const int *cbrow, const int *colidx_f, const uint8_t *type_f,
                            const double *doff, const uint8_t *mask)
 {
   // one thread per aggregate pair (I, J): its four coarse blocks (kind s of I, kind r of J) from one pass over the fine blocks
@@ -41,9 +44,9 @@ __global__ void k_galerkin(int npair, const int *prow, const int *crowptr, const
     const int i = cbrow[q], j = colidx_f[q];
     const int ti = type_f ? type_f[i] : 0, tj = type_f ? type_f[j] : 0;
     double m[9];
-    const double *bq = Kf + (size_t)q * 9;
+    const TIN *bq = Kf + (size_t)q * 9;
 #pragma unroll
-    for (int e = 0; e < 9; ++e) m[e] = bq[e];
+    for (int e = 0; e < 9; ++e) m[e] = (double)bq[e];
     if (mask) {
 #pragma unroll
       for (int a = 0; a < 3; ++a)
@@ -82,20 +85,21 @@ __global__ void k_galerkin(int npair, const int *prow, const int *crowptr, const
   const int k[4] = {base0 + 2 * t, base0 + 2 * t + 1, base1 + 2 * t, base1 + 2 * t + 1};
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
-    double *o = Kc + (size_t)k[w] * 9;
+    TOUT *o = Kc + (size_t)k[w] * 9;
 #pragma unroll
-    for (int e = 0; e < 9; ++e) o[e] = acc[w][e];
+    for (int e = 0; e < 9; ++e) o[e] = (TOUT)acc[w][e];
   }
 }
 
 // inverse of the diagonal 3x3 blocks; a singular block (aggregate made of
 // prescribed dofs only) gets the identity
-__global__ void k_block_inverse(int a0, int N, const int *diag, const double *K, double *minv)
+template <class TK>
+__global__ void k_block_inverse(int a0, int N, const int *diag, const TK *K, double *minv)
 {
   const int a = a0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= N) return;
   double d[9];
-  for (int t = 0; t < 9; ++t) d[t] = K[(size_t)diag[a] * 9 + t];
+  for (int t = 0; t < 9; ++t) d[t] = (double)K[(size_t)diag[a] * 9 + t];
   // rows/columns that are entirely zero (masked dofs on the coarse levels) become identity rows
   for (int i = 0; i < 3; ++i)
     if (d[3 * i + i] == 0.0) d[3 * i + i] = 1.0;
@@ -269,6 +273,7 @@ int amg_create(feahip_ctx *c)
   c->amg = h;
   h->row0 = c->row0; h->row1 = c->row1;
   { const char *e = getenv("FEAHIP_AMG_GAMMA"); if (e) h->gamma = atoi(e); }
+  { const char *e = getenv("FEAHIP_AMG_F32"); h->coarse_f32 = !(e && atoi(e) == 0); }
   { const char *e = getenv("FEAHIP_AMG_OVER"); if (e) h->over = atof(e); }
   { const char *e = getenv("FEAHIP_AMG_GAMMA_FROM"); if (e) h->gamma_from = atoi(e); }
   { const char *e = getenv("FEAHIP_AMG_SWEEPS"); if (e) h->coarse_sweeps = atoi(e); }
@@ -287,7 +292,11 @@ int amg_create(feahip_ctx *c)
       if ((rc = up(c, &L.colidx, S.colidx, h->bytes))) return rc;
       if ((rc = up(c, &L.diag, S.diag, h->bytes))) return rc;
       if ((rc = up(c, &L.chunk, S.chunk, h->bytes))) return rc;
-      if ((rc = zeros(c, &L.K, (size_t)L.nnzb * 9, h->bytes))) return rc;
+      if (h->coarse_f32) {
+        FEA_HIP_CHECK(c, hipMalloc((void **)&L.K32, sizeof(float) * ((size_t)L.nnzb * 9 + 4)));
+        FEA_HIP_CHECK(c, hipMemset(L.K32, 0, sizeof(float) * ((size_t)L.nnzb * 9 + 4)));
+        h->bytes += (long long)(sizeof(float) * (size_t)L.nnzb * 9);
+      } else if ((rc = zeros(c, &L.K, (size_t)L.nnzb * 9, h->bytes))) return rc;
       if ((rc = zeros(c, &L.r, (size_t)L.N * 3, h->bytes))) return rc;
       if ((rc = zeros(c, &L.x, (size_t)L.N * 3, h->bytes))) return rc;
       if ((rc = zeros(c, &L.y, (size_t)L.N * 3, h->bytes))) return rc;
@@ -317,7 +326,7 @@ void amg_destroy(feahip_ctx *c)
   for (AmgLevel &L : h->lv) {
     void *own[] = {L.minv, L.agg, L.doff, L.aptr, L.anodes, L.cbptr, L.cblist, L.prow, L.cbrow, L.r, L.x, L.y, L.type};
     for (void *p : own) if (p) (void)hipFree(p);
-    if (L.owns_matrix) { void *m[] = {L.rowptr, L.colidx, L.diag, L.chunk, L.K}; for (void *p : m) if (p) (void)hipFree(p); }
+    if (L.owns_matrix) { void *m[] = {L.rowptr, L.colidx, L.diag, L.chunk, L.K, L.K32}; for (void *p : m) if (p) (void)hipFree(p); }
   }
   if (h->d_z) (void)hipFree(h->d_z);
   if (h->d_pw) (void)hipFree(h->d_pw);
@@ -339,6 +348,12 @@ static LevelRange level_range(feahip_ctx *c, int l)
 }
 #define GROWS(R) G256((R).a1 - (R).a0)
 
+static void level_spmv(feahip_ctx *c, const AmgLevel &L, const LevelRange &R, const double *x, double *y)
+{
+  if (L.K32) enq_spmv_arrays_f32(c->stream, R.ch0, R.nch, L.chunk, L.rowptr, L.colidx, L.K32, x, y);
+  else enq_spmv_arrays(c->stream, R.ch0, R.nch, L.chunk, L.rowptr, L.colidx, L.K, x, y);
+}
+
 // coarse matrices, block inverses and the Jacobi damping of every level, for the current K
 static int amg_numeric(feahip_ctx *c)
 {
@@ -347,11 +362,17 @@ static int amg_numeric(feahip_ctx *c)
   for (int l = 0; l < nl; ++l) {
     AmgLevel &L = h->lv[l];
     const LevelRange R = level_range(c, l);
-    hipLaunchKernelGGL(k_block_inverse, GROWS(R), R.a0, R.a1, L.diag, L.K, L.minv);
+    if (L.K32) hipLaunchKernelGGL(k_block_inverse<float>, GROWS(R), R.a0, R.a1, L.diag, L.K32, L.minv);
+    else hipLaunchKernelGGL(k_block_inverse<double>, GROWS(R), R.a0, R.a1, L.diag, L.K, L.minv);
     if (L.Nc > 0) {
       AmgLevel &C = h->lv[l + 1];
-      hipLaunchKernelGGL(k_galerkin, G256(C.nnzb / 4), C.nnzb / 4, L.prow, C.rowptr, L.cbptr, L.cblist, L.K, C.K, L.cbrow, L.colidx,
-                         L.type, L.doff, l == 0 ? c->d_dofmask : (const uint8_t *)nullptr);
+      const uint8_t *gm = l == 0 ? c->d_dofmask : (const uint8_t *)nullptr;
+#define GALERKIN(TI, TO, KI, KO) hipLaunchKernelGGL((k_galerkin<TI, TO>), G256(C.nnzb / 4), C.nnzb / 4, L.prow, C.rowptr, L.cbptr, \
+                                                    L.cblist, KI, KO, L.cbrow, L.colidx, L.type, L.doff, gm)
+      if (L.K32 && C.K32) GALERKIN(float, float, L.K32, C.K32);
+      else if (C.K32) GALERKIN(double, float, L.K, C.K32);
+      else GALERKIN(double, double, L.K, C.K);
+#undef GALERKIN
     }
     // lambda_max(D^-1 K) by a few power iterations -> omega = 4 / (3 lambda_max)
     double *v = (l == 0) ? h->d_pw : L.x, *y = (l == 0) ? c->d_q : L.y;
@@ -359,7 +380,7 @@ static int amg_numeric(feahip_ctx *c)
     hipLaunchKernelGGL(k_fill_pattern, G256(n), 3 * R.a0, 3 * R.a1, n, v);
     double lam = 1.0;
     for (int it = 0; it < 8; ++it) {
-      enq_spmv_arrays(c->stream, R.ch0, R.nch, L.chunk, L.rowptr, L.colidx, L.K, v, y);
+      level_spmv(c, L, R, v, y);
       hipLaunchKernelGGL(k_apply_minv, GROWS(R), R.a0, R.a1, L.minv, y, v);
       const int nb = n >= 256 * 1024 ? 1024 : (n + 255) / 256;
       hipLaunchKernelGGL(k_norm2_partial, dim3(nb), dim3(256), 0, c->stream, n, v, c->d_part);
@@ -393,7 +414,7 @@ static void amg_cycle(feahip_ctx *c, int l, const double *r, double *x, double *
   hipLaunchKernelGGL(k_smooth_first, GROWS(R), R.a0, R.a1, L.omega, L.minv, r, x);
   if (L.Nc == 0) {
     for (int s = 0; s < h->coarse_sweeps; ++s) {
-      enq_spmv_arrays(c->stream, R.ch0, R.nch, L.chunk, L.rowptr, L.colidx, L.K, x, y);
+      level_spmv(c, L, R, x, y);
       hipLaunchKernelGGL(k_smooth_next, GROWS(R), R.a0, R.a1, L.omega, L.minv, r, y, x);
     }
     return;
@@ -401,14 +422,14 @@ static void amg_cycle(feahip_ctx *c, int l, const double *r, double *x, double *
   AmgLevel &C = h->lv[l + 1];
   const int gamma = (l < h->gamma_from) ? 1 : h->gamma;
   for (int g = 0; g < gamma; ++g) {
-    enq_spmv_arrays(c->stream, R.ch0, R.nch, L.chunk, L.rowptr, L.colidx, L.K, x, y);
+    level_spmv(c, L, R, x, y);
     hipLaunchKernelGGL(k_restrict, G256((C.N / 2) * 16), C.N / 2, L.aptr, L.anodes, L.type, L.doff, r, y, mask, C.r);
     amg_cycle(c, l + 1, C.r, C.x, C.y);
     // over-correction only where the correction is applied twice: (I - aE)^2 >= 0 for any a <= 2, while a single
     // over-corrected step can flip the sign of the preconditioner on part of the spectrum (seen: 6 492 iterations)
     hipLaunchKernelGGL(k_prolong, G256(L.N), L.N, L.agg, L.type, L.doff, C.x, mask, gamma >= 2 ? h->over : fmin(h->over, 1.0), x);
   }
-  enq_spmv_arrays(c->stream, R.ch0, R.nch, L.chunk, L.rowptr, L.colidx, L.K, x, y);
+  level_spmv(c, L, R, x, y);
   hipLaunchKernelGGL(k_smooth_next, GROWS(R), R.a0, R.a1, L.omega, L.minv, r, y, x);
 }
 

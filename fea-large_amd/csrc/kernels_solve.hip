@@ -171,9 +171,9 @@ int launch_update_nodes_solution(feahip_ctx *c, const double *d_uv)
 // (the 72-byte blocks of neighbouring lanes share cache lines, so the nine
 // strided loads of a wave hit L1 after the first touch).
 // ------------------------------------------------------------------------
-__global__ __launch_bounds__(256)
-void k_spmv(int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx, const double *K,
-            const double *x, double *y, const double *dotwith, double *part, const int *flag)
+template <class TK>
+__device__ __forceinline__ void spmv_body(int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx, const TK *K,
+                                          const double *x, double *y, const double *dotwith, double *part, const int *flag)
 {
   __shared__ double sP[FEA_WAVES_PER_WG][FEA_CHUNK_BLOCKS * 3];
   __shared__ double scratch[5];
@@ -191,9 +191,9 @@ void k_spmv(int chunk0, int nchunks, const int *chunk, const int *rowptr, const 
       const bool on = k < nb;
       const int kk = on ? b0 + k : b0;
       const int col = colidx[kk];
-      const double *vp = K + (size_t)kk * 9;
+      const TK *vp = K + (size_t)kk * 9;
 #pragma unroll
-      for (int q = 0; q < 9; ++q) v[h][q] = vp[q];
+      for (int q = 0; q < 9; ++q) v[h][q] = (double)vp[q];
 #pragma unroll
       for (int i = 0; i < 3; ++i) xv[h][i] = x[(size_t)col * 3 + i];
     }
@@ -221,6 +221,22 @@ void k_spmv(int chunk0, int nchunks, const int *chunk, const int *rowptr, const 
     const double s = block_sum(dsum, scratch);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
   }
+}
+
+__global__ __launch_bounds__(256)
+void k_spmv(int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx, const double *K,
+            const double *x, double *y, const double *dotwith, double *part, const int *flag)
+{
+  spmv_body<double>(chunk0, nchunks, chunk, rowptr, colidx, K, x, y, dotwith, part, flag);
+}
+
+// the same product with the matrix stored in single precision (coarse levels of the multigrid
+// preconditioner: half the bytes; vectors and arithmetic stay double)
+__global__ __launch_bounds__(256)
+void k_spmv_f32(int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx, const float *K,
+                const double *x, double *y)
+{
+  spmv_body<float>(chunk0, nchunks, chunk, rowptr, colidx, K, x, y, (const double *)nullptr, (double *)nullptr, (const int *)nullptr);
 }
 
 static int spmv_grid(const feahip_ctx *c)
@@ -746,6 +762,14 @@ int time_pcg_iteration(feahip_ctx *c, int warmup, int iters, double *avg_ms)
 }
 
 // y = K x on any level of a hierarchy (amg.hip): same kernel, explicit arrays
+void enq_spmv_arrays_f32(hipStream_t stream, int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx,
+                         const float *K, const double *xv, double *yv)
+{
+  int g = (nchunks + FEA_WAVES_PER_WG - 1) / FEA_WAVES_PER_WG;
+  g = g < FEA_RED_BLOCKS ? (g > 0 ? g : 1) : FEA_RED_BLOCKS;
+  hipLaunchKernelGGL(k_spmv_f32, dim3(g), dim3(256), 0, stream, chunk0, nchunks, chunk, rowptr, colidx, K, xv, yv);
+}
+
 void enq_spmv_arrays(hipStream_t stream, int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx,
                      const double *K, const double *xv, double *yv)
 {
