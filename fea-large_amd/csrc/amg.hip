@@ -205,6 +205,12 @@ __global__ void k_fill_pattern(int t0, int t1, int n, double *v)
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) v[t] = (t >= t0 && t < t1) ? 1.0 + 0.37 * (double)((t * 2654435761u) >> 24) / 256.0 : 0.0;   // fixed pseudo-random start
 }
+// single-precision copy of the fine matrix for the smoother of level 0 (the CG itself multiplies with the double one)
+__global__ void k_to_f32(size_t n, const double *src, float *dst)
+{
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) dst[t] = (float)src[t];
+}
+
 // |v|^2 in two stages with a fixed grid and order (deterministic)
 __global__ __launch_bounds__(256)
 void k_norm2_partial(int n, const double *v, double *part)
@@ -273,7 +279,7 @@ int amg_create(feahip_ctx *c)
   c->amg = h;
   h->row0 = c->row0; h->row1 = c->row1;
   { const char *e = getenv("FEAHIP_AMG_GAMMA"); if (e) h->gamma = atoi(e); }
-  { const char *e = getenv("FEAHIP_AMG_F32"); h->coarse_f32 = !(e && atoi(e) == 0); }
+  { const char *e = getenv("FEAHIP_AMG_F32"); h->coarse_f32 = !(e && atoi(e) == 0); h->fine_f32 = !(e && atoi(e) != 2); }
   { const char *e = getenv("FEAHIP_AMG_OVER"); if (e) h->over = atof(e); }
   { const char *e = getenv("FEAHIP_AMG_GAMMA_FROM"); if (e) h->gamma_from = atoi(e); }
   { const char *e = getenv("FEAHIP_AMG_SWEEPS"); if (e) h->coarse_sweeps = atoi(e); }
@@ -286,6 +292,11 @@ int amg_create(feahip_ctx *c)
     if (l == 0) {
       L.rowptr = c->d_rowptr; L.colidx = c->d_colidx; L.diag = c->d_diag; L.chunk = c->d_chunk; L.K = c->d_K;
       L.nchunks = c->nchunks;
+      if (h->coarse_f32 && h->fine_f32) {
+        FEA_HIP_CHECK(c, hipMalloc((void **)&L.K32, sizeof(float) * ((size_t)c->nnzb * 9 + 4)));
+        FEA_HIP_CHECK(c, hipMemset(L.K32, 0, sizeof(float) * ((size_t)c->nnzb * 9 + 4)));
+        h->bytes += (long long)(sizeof(float) * (size_t)c->nnzb * 9);
+      }
     } else {
       L.owns_matrix = true;
       if ((rc = up(c, &L.rowptr, S.rowptr, h->bytes))) return rc;
@@ -327,6 +338,7 @@ void amg_destroy(feahip_ctx *c)
     void *own[] = {L.minv, L.agg, L.doff, L.aptr, L.anodes, L.cbptr, L.cblist, L.prow, L.cbrow, L.r, L.x, L.y, L.type};
     for (void *p : own) if (p) (void)hipFree(p);
     if (L.owns_matrix) { void *m[] = {L.rowptr, L.colidx, L.diag, L.chunk, L.K, L.K32}; for (void *p : m) if (p) (void)hipFree(p); }
+    else if (L.K32) (void)hipFree(L.K32);
   }
   if (h->d_z) (void)hipFree(h->d_z);
   if (h->d_pw) (void)hipFree(h->d_pw);
@@ -362,14 +374,18 @@ static int amg_numeric(feahip_ctx *c)
   for (int l = 0; l < nl; ++l) {
     AmgLevel &L = h->lv[l];
     const LevelRange R = level_range(c, l);
-    if (L.K32) hipLaunchKernelGGL(k_block_inverse<float>, GROWS(R), R.a0, R.a1, L.diag, L.K32, L.minv);
+    if (l == 0 && L.K32) {                               // the rank's rows only
+      const size_t q0 = (size_t)c->h_rowptr[(size_t)h->row0] * 9, q1 = (size_t)c->h_rowptr[(size_t)h->row1] * 9;
+      hipLaunchKernelGGL(k_to_f32, dim3(4096), dim3(256), 0, c->stream, q1 - q0, (const double *)L.K + q0, L.K32 + q0);
+    }
+    if (l > 0 && L.K32) hipLaunchKernelGGL(k_block_inverse<float>, GROWS(R), R.a0, R.a1, L.diag, L.K32, L.minv);
     else hipLaunchKernelGGL(k_block_inverse<double>, GROWS(R), R.a0, R.a1, L.diag, L.K, L.minv);
     if (L.Nc > 0) {
       AmgLevel &C = h->lv[l + 1];
       const uint8_t *gm = l == 0 ? c->d_dofmask : (const uint8_t *)nullptr;
 #define GALERKIN(TI, TO, KI, KO) hipLaunchKernelGGL((k_galerkin<TI, TO>), G256(C.nnzb / 4), C.nnzb / 4, L.prow, C.rowptr, L.cbptr, \
                                                     L.cblist, KI, KO, L.cbrow, L.colidx, L.type, L.doff, gm)
-      if (L.K32 && C.K32) GALERKIN(float, float, L.K32, C.K32);
+      if (l > 0 && L.K32 && C.K32) GALERKIN(float, float, L.K32, C.K32);
       else if (C.K32) GALERKIN(double, float, L.K, C.K32);
       else GALERKIN(double, double, L.K, C.K);
 #undef GALERKIN
