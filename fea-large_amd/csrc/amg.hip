@@ -6,6 +6,8 @@
 // from kernels_solve.hip
 void enq_spmv_arrays(hipStream_t stream, int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx,
                      const double *K, const double *xv, double *yv);
+void enq_spmv_jacobi(hipStream_t stream, int nchunks, const int *chunk, const int *rowptr, const int *colidx, const double *K,
+                     const float *K32, const double *xin, double *xout, const double *r, const double *minv, double omega);
 void enq_spmv_arrays_f32(hipStream_t stream, int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx,
                          const float *K, const double *xv, double *yv);
 
@@ -428,6 +430,15 @@ static void amg_cycle(feahip_ctx *c, int l, const double *r, double *x, double *
   const uint8_t *mask = l == 0 ? c->d_dofmask : (const uint8_t *)nullptr;
   const LevelRange R = level_range(c, l);
   hipLaunchKernelGGL(k_smooth_first, GROWS(R), R.a0, R.a1, L.omega, L.minv, r, x);
+  if (L.Nc == 0 && l > 0 && (h->coarse_sweeps & 1) == 0) {
+    // coarsest level: product and damped Jacobi update in one launch per sweep, ping-pong between x and y
+    double *a = x, *b = y;
+    for (int s = 0; s < h->coarse_sweeps; ++s) {
+      enq_spmv_jacobi(c->stream, L.nchunks, L.chunk, L.rowptr, L.colidx, L.K, L.K32, a, b, r, L.minv, L.omega);
+      double *t = a; a = b; b = t;
+    }
+    return;                                            // an even number of sweeps ends in x
+  }
   if (L.Nc == 0) {
     for (int s = 0; s < h->coarse_sweeps; ++s) {
       level_spmv(c, L, R, x, y);

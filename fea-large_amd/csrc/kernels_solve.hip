@@ -239,6 +239,62 @@ void k_spmv_f32(int chunk0, int nchunks, const int *chunk, const int *rowptr, co
   spmv_body<float>(chunk0, nchunks, chunk, rowptr, colidx, K, x, y, (const double *)nullptr, (double *)nullptr, (const int *)nullptr);
 }
 
+// One damped block-Jacobi sweep fused with its product: xout = xin + omega D^-1 (r - K xin).  The product is the
+// SpMV above (wave per chunk, same partial products, same order); the rows of a chunk (<= 16, i.e. <= 48 lanes) then
+// exchange their three residual components by shuffles and apply the inverse diagonal block: one launch instead of
+// two, no y vector.  Used for the sweeps on the coarsest level of the multigrid cycle (96 launch pairs per cycle).
+template <class TK>
+__global__ __launch_bounds__(256)
+void k_spmv_jacobi(int nchunks, const int *chunk, const int *rowptr, const int *colidx, const TK *K,
+                   const double *xin, double *xout, const double *r, const double *minv, double omega)
+{
+  __shared__ double sP[FEA_WAVES_PER_WG][FEA_CHUNK_BLOCKS * 3];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double *tP = sP[wave];
+  for (int ch = blockIdx.x * FEA_WAVES_PER_WG + wave; ch < nchunks; ch += gridDim.x * FEA_WAVES_PER_WG) {
+    const int r0 = chunk[ch], r1 = chunk[ch + 1];
+    const int b0 = rowptr[r0], nb = rowptr[r1] - b0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = lane + 64 * h;
+      if (k < nb) {
+        const int kk = b0 + k;
+        const int col = colidx[kk];
+        const TK *vp = K + (size_t)kk * 9;
+        const double x0 = xin[(size_t)col * 3], x1 = xin[(size_t)col * 3 + 1], x2 = xin[(size_t)col * 3 + 2];
+        tP[k * 3 + 0] = (double)vp[0] * x0 + (double)vp[1] * x1 + (double)vp[2] * x2;
+        tP[k * 3 + 1] = (double)vp[3] * x0 + (double)vp[4] * x1 + (double)vp[5] * x2;
+        tP[k * 3 + 2] = (double)vp[6] * x0 + (double)vp[7] * x1 + (double)vp[8] * x2;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    const int t = lane, nt = (r1 - r0) * 3;              // <= 48: one pass
+    double res = 0.0;
+    const int row = r0 + t / 3, i = t % 3;
+    if (t < nt) {
+      const int kb = rowptr[row] - b0, ke = rowptr[row + 1] - b0;
+      double acc = 0;
+      for (int k = kb; k < ke; ++k) acc += tP[k * 3 + i];
+      res = r[(size_t)r0 * 3 + t] - acc;
+    }
+    const double t0 = __shfl(res, lane - i), t1 = __shfl(res, lane - i + 1), t2 = __shfl(res, lane - i + 2);
+    if (t < nt) {
+      const double *m = minv + (size_t)row * 9;
+      xout[(size_t)r0 * 3 + t] = xin[(size_t)r0 * 3 + t] + omega * (m[3 * i] * t0 + m[3 * i + 1] * t1 + m[3 * i + 2] * t2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  }
+}
+
+void enq_spmv_jacobi(hipStream_t stream, int nchunks, const int *chunk, const int *rowptr, const int *colidx, const double *K,
+                     const float *K32, const double *xin, double *xout, const double *r, const double *minv, double omega)
+{
+  int g = (nchunks + FEA_WAVES_PER_WG - 1) / FEA_WAVES_PER_WG;
+  g = g < FEA_RED_BLOCKS ? (g > 0 ? g : 1) : FEA_RED_BLOCKS;
+  if (K32) hipLaunchKernelGGL(k_spmv_jacobi<float>, dim3(g), dim3(256), 0, stream, nchunks, chunk, rowptr, colidx, K32, xin, xout, r, minv, omega);
+  else hipLaunchKernelGGL(k_spmv_jacobi<double>, dim3(g), dim3(256), 0, stream, nchunks, chunk, rowptr, colidx, K, xin, xout, r, minv, omega);
+}
+
 static int spmv_grid(const feahip_ctx *c)
 {
   int g = (c->nchunks_local + FEA_WAVES_PER_WG - 1) / FEA_WAVES_PER_WG;
