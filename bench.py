@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=None,
                     help="n of the CPU-baseline sample block (0 = skip; default: ~10 s of single-core work, 48 for TET4, 14 for TET10)")
     ap.add_argument("--no-newton", action="store_true", help="skip the single full Newton iteration")
+    ap.add_argument("--assembly", default="auto", help="assembly strategy: auto | gather | staged | ... (fea_hip.h)")
+    ap.add_argument("--numbering", default="brick", help="node numbering of the synthetic block: 'brick' = bricks of "
+                    "4x2x2 nodes (SURVEY 8d allows a locality numbering), 'lex' = x fastest, z, y slowest, or bx,by,bz")
     ap.add_argument("--cpu-single-only", action="store_true", help="skip the one-oracle-copy-per-core CPU baseline")
     args = ap.parse_args()
     if args.cpu_sample is None:
@@ -172,9 +175,13 @@ def main():
             dist.barrier()
 
     t_setup = time.perf_counter()
-    deck = mesh.bar_deck(n=args.n, quadratic=args.quadratic, recipe="clamped", model=model,
+    brick = None if args.numbering == "lex" else (4, 2, 2) if args.numbering == "brick" else tuple(int(v) for v in args.numbering.split(","))
+    if args.quadratic:
+        brick = None
+    deck = mesh.bar_deck(n=args.n, quadratic=args.quadratic, recipe="clamped", model=model, brick=brick,
                          solver_type=feahip.PCG_ILU, solver_tolerance=1e-14, solver_max_iter=20000)
     solver = feahip.FeaSolver(deck, device=local)
+    solver.set_assembly(getattr(feahip, "ASM_" + args.assembly.upper()))
     comm_ok = False
     if world > 1:
         # the timed assembly needs the row shard only (no collective); the RCCL communicator of the

@@ -89,6 +89,12 @@ struct feahip_ctx {
   uint32_t *d_qelem = nullptr, *d_qpair = nullptr;
   int *d_qnode = nullptr;
   long long quad_bytes = 0;
+  // GATHER assembly maps (linear tetrahedra, kernels_gather.hip): built for the rows this rank owns
+  bool have_gather = false, gather_failed = false;
+  int gather_row0 = -1, gather_row1 = -1, ngchunks = 0;
+  unsigned char *d_gmaps = nullptr;
+  struct GatherLayout *gather_lay = nullptr;
+  long long gather_bytes = 0;
   bool have_pairs = false;
   struct VisitDesc *d_pairdesc = nullptr;
   uint32_t *d_prec = nullptr;
@@ -225,6 +231,39 @@ struct HostQuad {
 };
 void build_host_quad(int N, int E, int npe, const int *conn, const HostPattern &hp, HostQuad &out);
 int launch_assemble_quad(feahip_ctx *c, bool doF);
+// GATHER assembly (kernels_gather.hip, gather.cpp): a 256-thread workgroup owns a run of consecutive block rows.
+// Per chunk the host prepares one fixed-stride record: header, the chunk's nodes (owned rows first), its distinct
+// elements as 4 chunk-local node ids, and per off-diagonal block the list of (element, local row node, local
+// column node) contributions that sum to it; per residual thread a slice of one row's (element, local node) visits.
+#define FEA_G_THREADS 256
+#define FEA_G_MAX_ROWS 16
+#define FEA_G_MAX_NODES 128
+#define FEA_G_MAX_ELEMS 255           // 8-bit element index; one more record slot is kept all-zero
+#define FEA_G_REGW 4                  // contribution words a block thread keeps in registers (2 entries each)
+struct GatherHeader {                // 64 bytes, first thing in a chunk record
+  int r0, r1, b0, nb;                // rows [r0, r1), blocks [b0, b0+nb) of the CSR
+  int nnode, nelem, noffd, depth;    // depth: contribution words per block thread
+  int nvthr, vdepth;                 // residual threads, visits per residual thread
+  int pad[6];
+};
+struct GatherLayout {                // the same for every chunk of a context
+  int stride;                        // bytes per chunk record
+  int o_nodes, o_elems, o_bpos, o_rows, o_vlist, o_clist;   // byte offsets of the sections
+  int max_nodes, max_elems, max_tile;                        // LDS tiles: coordinates, element records, K blocks
+  int max_tasks, max_depth, max_vthr, max_vdepth;            // largest chunk: block threads, contribution words, residual threads, visits
+};
+struct HostGather {
+  GatherLayout lay;
+  std::vector<unsigned char> blob;   // nchunks records of lay.stride bytes
+  std::vector<int> first_row;        // [nchunks+1]
+  int nchunks = 0;
+  bool ok = false;
+};
+// rows [row_lo, row_hi) only: a rank builds the maps of the rows it owns
+void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int row_lo, int row_hi, HostGather &out);
+int ensure_gather(feahip_ctx *c);
+int launch_assemble_gather(feahip_ctx *c, bool doK, bool doF);
+
 struct HostPairs {
   std::vector<VisitDesc> desc;       // visit_off / nvisit = first pair / pairs of the chunk
   std::vector<uint32_t> prec;        // [4 * pairs]: ids a,p,q,r | s,flags | slots p,q,r,s | 0

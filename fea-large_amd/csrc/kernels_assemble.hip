@@ -309,6 +309,15 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
     FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));
     return launch_assemble_quad(c, doF);
   }
+  if (strat == FEAHIP_ASM_GATHER) {
+    { const int rc = ensure_gather(c); if (rc) return rc; }
+    if (!c->have_gather) {
+      c->err = "gather assembly needs linear tetrahedra (one Gauss point) whose rows fit the LDS tiles";
+      return FEAHIP_EINVAL;
+    }
+    if (doK) FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));
+    return launch_assemble_gather(c, doK, doF);
+  }
   if (strat == FEAHIP_ASM_PAIRED) {
     { const int rc = ensure_pairs(c); if (rc) return rc; }
     if (!c->have_pairs) {

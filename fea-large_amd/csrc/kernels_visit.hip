@@ -425,26 +425,40 @@ int launch_assemble_visit(feahip_ctx *c, bool doK, bool doF, bool pipelined)
   A.lambda = c->lambda; A.mu = c->mu; A.tab = c->d_table; A.desc = c->d_vdesc; A.vnode = c->d_vnode;
   A.vrec = reinterpret_cast<const uint2 *>(c->d_vrec); A.X0 = c->d_X0; A.x = c->d_x;
   A.rowptr = c->d_rowptr; A.diag = c->d_diag; A.nvisits = c->nvisit_records; A.nrows_total = c->N; A.K = c->d_K; A.f = c->d_f; A.bad = c->d_flag + 1;
+  A.dbg = 0; A.stamps = nullptr;
+#ifdef FEAHIP_DEBUG
+  // Diagnostic build only (make debug -> libfeahip_dbg.so): FEAHIP_DBG selects the timing experiments of DESIGN.md,
+  // whose K and f are meaningless.  The production library has neither the lookup nor the instantiations.
   { const char *e = getenv("FEAHIP_DBG"); A.dbg = e ? atoi(e) : 0; }
   static unsigned long long *d_stamps = nullptr;
-  if ((A.dbg & 4) && !d_stamps) (void)hipMalloc((void **)&d_stamps, sizeof(unsigned long long) * 8 * (size_t)c->nachunks);
+  static int stamps_cap = 0;
+  if ((A.dbg & 4) && (!d_stamps || stamps_cap < c->nachunks)) {
+    if (d_stamps) (void)hipFree(d_stamps);
+    (void)hipMalloc((void **)&d_stamps, sizeof(unsigned long long) * 8 * (size_t)c->nachunks);
+    stamps_cap = c->nachunks;
+  }
   A.stamps = d_stamps;
+#endif
   if (c->nachunks_local <= 0) return FEAHIP_OK;
   static int run_len = -1;           // chunks per wave of the pipelined kernel (FEAHIP_RUN: tuning only)
   if (run_len < 0) { const char *e = getenv("FEAHIP_RUN"); run_len = e && atoi(e) > 0 ? atoi(e) : 6; }
   if (pipelined && !(A.dbg & ~5)) {
     const int nruns = (c->nachunks_local + run_len - 1) / run_len;
     const dim3 rgrid((nruns + 7) & ~7), rblk(64);
+#ifdef FEAHIP_DEBUG
     if (A.dbg) {
       if (doK && doF) hipLaunchKernelGGL((k_assemble_run<true, true, true>), rgrid, rblk, 0, c->stream, A, run_len);
       else if (doK)   hipLaunchKernelGGL((k_assemble_run<true, false, true>), rgrid, rblk, 0, c->stream, A, run_len);
       else            hipLaunchKernelGGL((k_assemble_run<false, true, true>), rgrid, rblk, 0, c->stream, A, run_len);
-    } else {
+    } else
+#endif
+    {
       if (doK && doF) hipLaunchKernelGGL((k_assemble_run<true, true, false>), rgrid, rblk, 0, c->stream, A, run_len);
       else if (doK)   hipLaunchKernelGGL((k_assemble_run<true, false, false>), rgrid, rblk, 0, c->stream, A, run_len);
       else            hipLaunchKernelGGL((k_assemble_run<false, true, false>), rgrid, rblk, 0, c->stream, A, run_len);
     }
     FEA_HIP_CHECK(c, hipGetLastError());
+#ifdef FEAHIP_DEBUG
     if (A.dbg & 4) {                                  // diagnostic path: phase shares, never a timing
       static int printed = 0;
       (void)hipStreamSynchronize(c->stream);
@@ -458,19 +472,24 @@ int launch_assemble_visit(feahip_ctx *c, bool doK, bool doF, bool pipelined)
                 run_len, sum[0] / c->nachunks_local, sum[1] / c->nachunks_local, sum[2] / c->nachunks_local, sum[4] / c->nachunks_local);
       }
     }
+#endif
     return FEAHIP_OK;
   }
   const dim3 grid((c->nachunks_local + 7) & ~7), blk(64);
+#ifdef FEAHIP_DEBUG
   if (A.dbg) {
     if (doK && doF) hipLaunchKernelGGL((k_assemble_visit<true, true, true>), grid, blk, 0, c->stream, A);
     else if (doK)   hipLaunchKernelGGL((k_assemble_visit<true, false, true>), grid, blk, 0, c->stream, A);
     else            hipLaunchKernelGGL((k_assemble_visit<false, true, true>), grid, blk, 0, c->stream, A);
-  } else {
+  } else
+#endif
+  {
     if (doK && doF) hipLaunchKernelGGL((k_assemble_visit<true, true, false>), grid, blk, 0, c->stream, A);
     else if (doK)   hipLaunchKernelGGL((k_assemble_visit<true, false, false>), grid, blk, 0, c->stream, A);
     else            hipLaunchKernelGGL((k_assemble_visit<false, true, false>), grid, blk, 0, c->stream, A);
   }
   FEA_HIP_CHECK(c, hipGetLastError());
+#ifdef FEAHIP_DEBUG
   if (A.dbg & 4) {                                  // diagnostic build path: phase shares, never a timing
     static int printed = 0;
     (void)hipStreamSynchronize(c->stream);
@@ -489,5 +508,6 @@ int launch_assemble_visit(feahip_ctx *c, bool doK, bool doF, bool pipelined)
               sum[2] / c->nachunks_local, sum[3] / c->nachunks_local, sum[4] / c->nachunks_local, tmax - tmin);
     }
   }
+#endif
   return FEAHIP_OK;
 }

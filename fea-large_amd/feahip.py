@@ -12,12 +12,13 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfeahip.so")
+# FEAHIP_LIB: measurement tooling only (the diagnostic build libfeahip_dbg.so); still a HIP library, never a fallback
+LIB_PATH = os.environ.get("FEAHIP_LIB") or os.path.join(_HERE, "libfeahip.so")
 HOST_LIB_PATH = os.path.join(_HERE, "libfeahost.so")
 
 MODEL_A5, MODEL_COMPRESSIBLE_NEOHOOKEAN = 0, 1
 CG, PCG_ILU, CHOLESKY = 0, 1, 2
-ASM_AUTO, ASM_ROWOWNER, ASM_ATOMIC, ASM_PATCH, ASM_STAGED, ASM_PAIRED, ASM_PIPELINED, ASM_SHARED = 0, 1, 2, 3, 4, 5, 6, 7
+ASM_AUTO, ASM_ROWOWNER, ASM_ATOMIC, ASM_PATCH, ASM_STAGED, ASM_PAIRED, ASM_PIPELINED, ASM_SHARED, ASM_GATHER = 0, 1, 2, 3, 4, 5, 6, 7, 8
 TETRAHEDRA10, TETRAHEDRA4 = 0, 1
 
 _dp = C.POINTER(C.c_double)

@@ -46,8 +46,29 @@ def block_dims(n):
     return n, 6 * n, n
 
 
-def kuhn_block(nx, ny, nz, quadratic=False, origin=(0.0, 1.0, 0.0), size=(1.0, 6.0, 1.0)):
-    """(nodes[N][3], elements[E][4 or 10]) of the block."""
+def brick_numbering(gx, gy, gz, brick):
+    """new id of every lexicographic node id (x fastest, then z, y slowest) when the grid is numbered brick by
+    brick: bricks of bx x by x bz nodes in the same lexicographic order, nodes inside a brick likewise.  A
+    contiguous id range is then a spatially compact cluster (what the assembly kernel's chunks want: fewer
+    elements touch a chunk's rows) and still a slab across the long axis (what the row shard cuts).
+    SURVEY.md 8(d) allows a locality numbering of the synthetic blocks; which one is used is reported."""
+    bx, by, bz = brick
+    ids = np.arange(gx * gy * gz, dtype=np.int64)
+    i, k, j = ids % gx, (ids // gx) % gz, ids // (gx * gz)
+    bi, bk, bj = i // bx, k // bz, j // by
+    li, lk, lj = i % bx, k % bz, j % by
+    wx = np.minimum(bx, gx - bi * bx)                  # the last brick along an axis may be thinner
+    wz = np.minimum(bz, gz - bk * bz)
+    key = np.lexsort((li, lk, lj, bi, bk, bj))           # last key is the slowest
+    new_id = np.empty_like(ids)
+    new_id[key] = ids
+    del wx, wz
+    return new_id
+
+
+def kuhn_block(nx, ny, nz, quadratic=False, origin=(0.0, 1.0, 0.0), size=(1.0, 6.0, 1.0), brick=None):
+    """(nodes[N][3], elements[E][4 or 10]) of the block; brick = (bx, by, bz) numbers the nodes brick by brick
+    (brick_numbering) instead of lexicographically."""
     off = _kuhn_corner_offsets()
     m = 2 if quadratic else 1          # grid refinement: TET10 nodes live on the half-spacing grid
     gx, gy, gz = m * nx + 1, m * ny + 1, m * nz + 1
@@ -73,6 +94,12 @@ def kuhn_block(nx, ny, nz, quadratic=False, origin=(0.0, 1.0, 0.0), size=(1.0, 6
     nodes[:, 0] = origin[0] + size[0] * i.ravel() / (gx - 1)
     nodes[:, 1] = origin[1] + size[1] * j.ravel() / (gy - 1)
     nodes[:, 2] = origin[2] + size[2] * k.ravel() / (gz - 1)
+    if brick is not None:
+        new_id = brick_numbering(gx, gy, gz, brick)
+        elements = new_id[elements].astype(np.int32)
+        out = np.empty_like(nodes)
+        out[new_id] = nodes
+        nodes = out
     return nodes, elements
 
 
@@ -113,9 +140,9 @@ def increment_for(n):
 
 
 def bar_deck(n=None, dims=None, quadratic=False, recipe="clamped", model=MODEL_COMPRESSIBLE_NEOHOOKEAN,
-             gauss=None, dy=None, **kw):
+             gauss=None, dy=None, brick=None, **kw):
     nx, ny, nz = dims if dims is not None else block_dims(n)
-    nodes, elements = kuhn_block(nx, ny, nz, quadratic)
+    nodes, elements = kuhn_block(nx, ny, nz, quadratic, brick=brick)
     if dy is None:
         dy = increment_for(max(nx, nz))
     ids, types, vals = bar_boundary(nodes, recipe, dy)

@@ -60,10 +60,17 @@ enum {
                               under the current one; hides the load latency
                               but the LDS adds bound both: equal to STAGED
                               within 2 %                         */
-  FEAHIP_ASM_SHARED = 7    /* 10-node tets: Gauss-point states evaluated once
+  FEAHIP_ASM_SHARED = 7,   /* 10-node tets: Gauss-point states evaluated once
                               per chunk element and shared through LDS, the
                               blocks of a (row, element, column) pair summed
                               over the Gauss points in registers              */
+  FEAHIP_ASM_GATHER = 8    /* linear tets: a 256-thread workgroup owns a run
+                              of block rows; every element touching them is
+                              evaluated once into an LDS record, one thread
+                              per off-diagonal block then sums that block's
+                              element contributions in registers.  No
+                              atomics anywhere, fixed summation order:
+                              bitwise reproducible                           */
 };
 
 /* ---- lifetime ----------------------------------------------------------- */

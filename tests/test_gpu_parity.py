@@ -37,7 +37,7 @@ def make_pair(deck, x=None):
 
 def check_assembly(s, o, strategies=(feahip.ASM_ROWOWNER, feahip.ASM_ATOMIC)):
     if s.npe == 4 and s.G == 1:
-        strategies = tuple(strategies) + (feahip.ASM_PATCH, feahip.ASM_STAGED, feahip.ASM_PAIRED, feahip.ASM_PIPELINED)
+        strategies = tuple(strategies) + (feahip.ASM_PATCH, feahip.ASM_STAGED, feahip.ASM_PAIRED, feahip.ASM_PIPELINED, feahip.ASM_GATHER)
     if s.npe == 10:
         strategies = tuple(strategies) + (feahip.ASM_SHARED,)
     o.update_state()
@@ -108,6 +108,22 @@ def test_patch_assembly_is_bitwise_reproducible():
     assert np.array_equal(v1, s.matrix_yale()[2]) and np.array_equal(f1, s.forces())
     s.create_stiffness()                                  # K alone: same bits
     assert np.array_equal(v1, s.matrix_yale()[2])
+    s.close()
+
+
+def test_gather_assembly_is_bitwise_reproducible():
+    deck = mesh.bar_deck(dims=(7, 13, 5))
+    s = feahip.FeaSolver(deck)
+    s.set_nodes(mesh.deformed_state(deck.nodes))
+    s.set_assembly(feahip.ASM_GATHER)
+    s.create_stiffness_and_residual()
+    v1, f1 = s.matrix_yale()[2], s.forces()
+    s.create_stiffness_and_residual()
+    assert np.array_equal(v1, s.matrix_yale()[2]) and np.array_equal(f1, s.forces())
+    s.create_stiffness()                                  # K alone: same bits
+    assert np.array_equal(v1, s.matrix_yale()[2])
+    s.create_residual_forces()                            # f alone: a different record, same sums to rounding
+    assert rel(s.forces(), f1) < 1e-14
     s.close()
 
 
