@@ -42,17 +42,21 @@ def spmv_bytes(nnz, N):
     return 8 * nnz + 4 * nnz // 9 + 4 * (N + 1) + 48 * N
 
 
-def pmc_traffic(args, world):
+def pmc_traffic(args, world, kernel):
     """HBM bytes per assembly launch from rocprofv3 PMC counters (FETCH_SIZE + WRITE_SIZE, separate passes,
-    tools/pmc_profile.sh).  bench.py cannot collect PMC itself: the number is the one measured for the
-    default configuration this round (profiles/), and null for any other configuration."""
+    tools/pmc_profile.sh, corrected as MI355X_MICROARCH.md prescribes).  bench.py cannot collect PMC itself: the
+    number is the one measured for THIS kernel and configuration (profiles/pmc_traffic.json carries the kernel, the
+    numbering and the commit it was measured at), and null for anything else.  Returns (bytes, provenance)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if world != 1 or args.n != 66 or args.quadratic or args.model != "neohookean" or not os.path.exists(path):
-        return None
+        return None, None
     try:
-        return json.load(open(path))["assembly_bytes_per_launch"]
+        rec = json.load(open(path))
+        if rec.get("kernel") != kernel or rec.get("numbering") != args.numbering:
+            return None, None
+        return rec["assembly_bytes_per_launch"], {k: rec.get(k) for k in ("commit", "source", "fetch_correction")}
     except Exception:                               # noqa: BLE001
-        return None
+        return None, None
 
 
 def cpu_baseline(n_sample, quadratic=False, model=None):
@@ -180,6 +184,7 @@ def main():
         brick = None
     deck = mesh.bar_deck(n=args.n, quadratic=args.quadratic, recipe="clamped", model=model, brick=brick,
                          solver_type=feahip.PCG_ILU, solver_tolerance=1e-14, solver_max_iter=20000)
+    free0 = torch.cuda.mem_get_info(local)[0]
     solver = feahip.FeaSolver(deck, device=local)
     solver.set_assembly(getattr(feahip, "ASM_" + args.assembly.upper()))
     comm_ok = False
@@ -188,8 +193,15 @@ def main():
         # sharded solve is built afterwards, under the watchdog, so a wedged rendezvous cannot cost the line
         solver.set_row_shard(rank, world)
     solver.set_nodes(mesh.deformed_state(deck.nodes))
+    solver.create_stiffness_and_residual()              # builds the assembly maps of the rows this rank owns
+    solver.sync()
     sz = solver.sizes()
     t_setup = time.perf_counter() - t_setup
+    dev_bytes = free0 - torch.cuda.mem_get_info(local)[0]
+    in_use = solver.assembly_in_use()
+    kernel = {feahip.ASM_GATHER: "k_assemble_gather", feahip.ASM_STAGED: "k_assemble_visit", feahip.ASM_PIPELINED: "k_assemble_run",
+              feahip.ASM_SHARED: "k_assemble_quad", feahip.ASM_PATCH: "k_assemble_patch", feahip.ASM_PAIRED: "k_assemble_pair",
+              feahip.ASM_ATOMIC: "k_assemble_atomic"}.get(in_use, "k_assemble_rowowner")
 
     E_total, N, nnz = sz["E"], sz["N"], sz["nnzb"] * 9
     # The device needs ~25 back-to-back launches (~30 ms of load) to reach its sustained clocks: the rocprofv3 trace
@@ -232,7 +244,11 @@ def main():
         "setup_s": t_setup,
         "aux_map_bytes_per_element": sz["aux_bytes"] / E_total,
         "rccl_sharded_solve": comm_ok if world > 1 else None,
+        "device_bytes_this_rank": int(dev_bytes),
+        "node_numbering": ("lexicographic (x fastest, z, y slowest)" if brick is None else
+                           "bricks of %dx%dx%d nodes, bricks and nodes inside a brick lexicographic (SURVEY 8d allows a locality numbering)" % brick),
     }
+    traffic, traffic_src = pmc_traffic(args, world, kernel)
     out = {
         "metric": "element-stiffness assemblies/sec", "value": value, "unit": "elements/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -245,9 +261,8 @@ def main():
                    "sharding": f"block rows in {world} slab(s) across y, ghost elements recomputed, "
                                f"no collective in assembly"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, world),
-                     "kernel": "k_assemble_visit" if not args.quadratic else "k_assemble_quad",
-                     "algorithmic_bytes_per_launch": B},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": kernel, "algorithmic_bytes_per_launch": B},
         "extras": extras,
     }
 
@@ -260,27 +275,38 @@ def main():
 
     # The sharded solve is a bonus leg: a watchdog prints the line and leaves if a collective wedges.
     def bail():
-        extras["solve_leg"] = "timed out"
+        extras["solve_leg"] = "timed out (a collective or the solve wedged): the assembly figures above stand, the solve leg does not"
         emit()
-        os._exit(0)
+        os._exit(3)
 
     watchdog = threading.Timer(240.0, bail)
     watchdog.daemon = True
     watchdog.start()
+    rc_exit = 0
     if world > 1:
-        # RCCL communicator for the sharded linear solve (halo rows + scalar all-reduces)
-        try:
-            uid = [feahip.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            solver.comm_init(rank, world, uid[0])
-            comm_ok = True
-        except Exception as e:                      # noqa: BLE001
-            print(f"[rank {rank}] RCCL communicator unavailable ({e}); assembly-only sharding", file=sys.stderr)
-            solver.set_row_shard(rank, world)
+        # RCCL communicator for the sharded linear solve (halo rows + scalar all-reduces).  RCCL refuses ranks that
+        # share a device, so the gloo rehearsal (several ranks on one GPU) does not attempt it.
+        why = None
+        if backend != "nccl":
+            why = "not attempted: ranks share a device in the %s rehearsal" % backend
+        else:
+            try:
+                uid = [feahip.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                solver.comm_init(rank, world, uid[0])
+                comm_ok = True
+            except Exception as e:                  # noqa: BLE001
+                why = f"rccl init failed on rank {rank}: {e}"
+                print(f"[rank {rank}] {why}", file=sys.stderr)
+                solver.set_row_shard(rank, world)
         flags = [None] * world
-        dist.all_gather_object(flags, comm_ok)
-        comm_ok = all(flags)
+        dist.all_gather_object(flags, (comm_ok, why))
+        comm_ok = all(f[0] for f in flags)
         extras["rccl_sharded_solve"] = comm_ok
+        if not comm_ok:
+            extras["solve_leg"] = next(f[1] for f in flags if not f[0])
+            if backend == "nccl":
+                rc_exit = 4                         # the line is printed, but a dead solve path is a failed run
     if world == 1 or comm_ok:
         try:
             extras["pcg_iteration_ms"] = solver.time_kernel(4, warmup=2, iters=10)      # collective when sharded
@@ -302,7 +328,8 @@ def main():
                 tn, its, res, en = newton_iteration()
                 extras.update({"newton_iters_per_s": 1.0 / tn, "newton_iteration_s": tn, "cg_iterations": its,
                                "cg_relative_residual": res, "energy_u_f": en,
-                               "newton_preconditioner": "3x3 block-Jacobi"})
+                               "newton_preconditioner": "3x3 block-Jacobi",
+                               "newton_iters_per_s_block_jacobi": 1.0 / tn})
                 if True:
                     # same iteration with the aggregation-multigrid preconditioner: sharded, every rank runs the
                     # W-cycle on its own diagonal block (block-Jacobi over the ranks, no collective inside it)
@@ -315,11 +342,13 @@ def main():
                     extras.update({"newton_iters_per_s": 1.0 / tn, "newton_iteration_s": tn, "cg_iterations": its,
                                    "cg_relative_residual": res, "energy_u_f": en2,
                                    "newton_preconditioner": "aggregation multigrid (rigid-body modes), W-cycle",
+                                   "newton_iters_per_s_multigrid": 1.0 / tn,
                                    "amg_setup_s": t_amg,
                                    "energy_u_f_block_jacobi": en})
                     solver.set_preconditioner(0)
         except Exception as e:                      # noqa: BLE001
             extras["solve_leg"] = f"failed: {e}"
+            rc_exit = 5
     watchdog.cancel()
     if rank == 0 and args.cpu_sample > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.quadratic, model)
@@ -335,6 +364,8 @@ def main():
             dist.destroy_process_group()
         except Exception:                           # noqa: BLE001
             pass
+    if rc_exit:
+        sys.exit(rc_exit)
 
 
 if __name__ == "__main__":

@@ -25,6 +25,7 @@ int install_shard(feahip_ctx *c, int rank, int nranks)
   }
   ShardPlan plan;
   build_shard_plan(c->h_rowptr, c->h_colidx, c->h_chunk, rank, nranks, plan);
+  if (plan.row0 != c->row0 || plan.row1 != c->row1) release_k(c);     // K is re-allocated for the new rows on next use
   c->rank = rank; c->nranks = nranks; c->row0 = plan.row0; c->row1 = plan.row1;
   c->peer = plan.peer; c->send_off = plan.send_off; c->recv_off = plan.recv_off;
   c->nsend = (int)plan.send_idx.size(); c->nrecv = (int)plan.recv_idx.size();

@@ -57,8 +57,45 @@ int ensure_patches(feahip_ctx *c)
   return FEAHIP_OK;
 }
 
+// K for the rows of the shard installed now (see feahip_internal.h)
+int ensure_k(feahip_ctx *c)
+{
+  if (c->d_K_base) return FEAHIP_OK;
+  c->kb0 = c->h_rowptr[c->row0]; c->kb1 = c->h_rowptr[c->row1];
+  const size_t n = (size_t)(c->kb1 - c->kb0) * 9 + 2;       // +2: the SpMV reads aligned 80-byte windows
+  FEA_HIP_CHECK(c, hipMalloc((void **)&c->d_K_base, sizeof(double) * n));
+  FEA_HIP_CHECK(c, hipMemset(c->d_K_base, 0, sizeof(double) * n));
+  c->d_K = c->d_K_base - (size_t)c->kb0 * 9;
+  return FEAHIP_OK;
+}
+
+void release_k(feahip_ctx *c)
+{
+  if (c->d_K_base) (void)hipFree(c->d_K_base);
+  if (c->d_Kstash_base) (void)hipFree(c->d_Kstash_base);
+  c->d_K_base = c->d_Kstash_base = c->d_K = c->d_Kstash = nullptr;
+  c->have_stash = false; c->k_bc = false; ++c->k_epoch;
+}
+
+int ensure_visits(feahip_ctx *c)
+{
+  if (c->have_visits || c->visits_failed || !c->h_pat || c->h_conn.empty()) return FEAHIP_OK;
+  HostVisits hv;
+  build_host_visits(c->N, c->E, c->h_conn.data(), *c->h_pat, hv);
+  if (!hv.ok) { c->visits_failed = true; return FEAHIP_OK; }
+  int rc;
+  if ((rc = dev_upload(c, &c->d_vdesc, hv.desc.data(), hv.desc.size()))) return rc;
+  if ((rc = dev_upload(c, &c->d_vnode, hv.vnode.data(), hv.vnode.size()))) return rc;
+  if ((rc = dev_upload(c, &c->d_vrec, hv.vrec.data(), hv.vrec.size()))) return rc;
+  c->have_visits = true;
+  c->nvisit_records = (int)(hv.vrec.size() / 2);
+  c->visit_bytes = (long long)(hv.desc.size() * sizeof(VisitDesc) + hv.vnode.size() * 4 + hv.vrec.size() * 4);
+  return FEAHIP_OK;
+}
+
 int ensure_pairs(feahip_ctx *c)
 {
+  { const int rc = ensure_visits(c); if (rc) return rc; }
   if (c->have_pairs || !c->have_visits || !c->h_pat || c->h_conn.empty()) return FEAHIP_OK;
   HostVisits hv;                                    // the pairing starts from the visit maps: built again, host only
   build_host_visits(c->N, c->E, c->h_conn.data(), *c->h_pat, hv);
@@ -148,20 +185,11 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
   c->aux_bytes = (long long)(hp.incptr.size() * 4 + hp.inc.size() * 4 + hp.incslot.size() +
                              hp.chunk.size() * 4 + hp.rowptr.size() * 4 + hp.diag.size() * 4);
 
-  if (c->linear_tet && gauss_count == 1) {
-    HostVisits hv;
-    build_host_visits(n_nodes, n_elems, elements, hp, hv);
-    if (hv.ok) {
-      if ((rc = dev_upload(c, &c->d_vdesc, hv.desc.data(), hv.desc.size()))) return rc;
-      if ((rc = dev_upload(c, &c->d_vnode, hv.vnode.data(), hv.vnode.size()))) return rc;
-      if ((rc = dev_upload(c, &c->d_vrec, hv.vrec.data(), hv.vrec.size()))) return rc;
-      c->have_visits = true;
-      c->nvisit_records = (int)(hv.vrec.size() / 2);
-      c->visit_bytes = (long long)(hv.desc.size() * sizeof(VisitDesc) + hv.vnode.size() * 4 + hv.vrec.size() * 4);
-    }
-  }
-  if (c->have_visits) {
-    // the default path is complete; everything else is built on demand from these
+  const bool lin1 = c->linear_tet && gauss_count == 1;
+  if (lin1) {
+    // the maps of every linear-tet strategy (gather, staged visits, patches, pairs, generic incidence lists) are
+    // built the first time a launch asks for them, from these host copies -- for the rows this rank owns where
+    // the strategy allows (gather)
     c->h_conn.assign(elements, elements + (size_t)n_elems * npe);
   } else if ((rc = ensure_generic_maps(c))) return rc;
   if (npe == 10) {
@@ -176,8 +204,7 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
       c->quad_bytes = (long long)(hq.desc.size() * sizeof(QuadDesc) + hq.qelem.size() * 4 + hq.qpair.size() * 4 + hq.qnode.size() * 4);
     }
   }
-  if (!c->have_visits) { delete c->h_pat; c->h_pat = nullptr; }          // nothing is built later for these meshes
-  if ((rc = dev_zeros(c, &c->d_K, (size_t)c->nnzb * 9 + 2))) return rc;   // +2: the SpMV reads aligned 80-byte windows
+  if (!lin1) { delete c->h_pat; c->h_pat = nullptr; }          // nothing is built later for these meshes
   if ((rc = dev_zeros(c, &c->d_f, (size_t)c->ndof))) return rc;
   if ((rc = dev_zeros(c, &c->d_u, (size_t)c->ndof))) return rc;
   if ((rc = dev_zeros(c, &c->d_r, (size_t)c->ndof))) return rc;
@@ -240,7 +267,7 @@ extern "C" void feahip_destroy(feahip_ctx *c)
   if (!c) return;
   delete c->h_pat; c->h_pat = nullptr;
   delete c->gather_lay; c->gather_lay = nullptr;
-  void *ptrs[] = {(void *)c->d_gmaps, c->d_table, c->d_conn, c->d_X0, c->d_x, c->d_rowptr, c->d_colidx, c->d_K, c->d_Kstash,
+  void *ptrs[] = {(void *)c->d_gmaps, c->d_table, c->d_conn, c->d_X0, c->d_x, c->d_rowptr, c->d_colidx, c->d_K_base, c->d_Kstash_base,
                   c->d_incptr, c->d_inc, c->d_incslot, c->d_chunk, c->d_diag, c->d_pdesc, c->d_pnode, c->d_pelem, c->d_pent, c->d_pbptr, c->d_vdesc, c->d_vnode, c->d_vrec, c->d_pairdesc, c->d_prec, c->d_qdesc, c->d_qelem, c->d_qpair, c->d_qnode, c->d_f, c->d_u, c->d_r, c->d_p,
                   c->d_q, c->d_minv, c->d_part, c->d_scal, c->d_flag, c->d_cdof, c->d_cval,
                   c->d_dofmask, c->d_F, c->d_S};
@@ -254,20 +281,24 @@ extern "C" void feahip_destroy(feahip_ctx *c)
   delete c;
 }
 
-#define CTX_GUARD(c)                              \
+#define CTX_GUARD_NOK(c)                          \
   if (!(c)) return FEAHIP_EINVAL;                 \
   FEA_HIP_CHECK(c, hipSetDevice((c)->device))
+// entry points that read or write K make sure it exists for the shard installed now
+#define CTX_GUARD(c)                              \
+  CTX_GUARD_NOK(c);                               \
+  { const int _rk = ensure_k(c); if (_rk) return _rk; }
 
 extern "C" int feahip_sync(feahip_ctx *c)
 {
-  CTX_GUARD(c);
+  CTX_GUARD_NOK(c);
   FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
   return FEAHIP_OK;
 }
 
 extern "C" int feahip_set_assembly(feahip_ctx *c, int strategy)
 {
-  CTX_GUARD(c);
+  CTX_GUARD_NOK(c);
   if (strategy < FEAHIP_ASM_AUTO || strategy > FEAHIP_ASM_GATHER) { c->err = "unknown assembly strategy"; return FEAHIP_EINVAL; }
   c->strategy = strategy;
   return FEAHIP_OK;
@@ -284,7 +315,7 @@ extern "C" int feahip_set_preconditioner(feahip_ctx *c, int kind)
 
 extern "C" int feahip_set_line_search(feahip_ctx *c, int max_iterations)
 {
-  CTX_GUARD(c);
+  CTX_GUARD_NOK(c);
   if (max_iterations < 0) { c->err = "line search iterations must be >= 0"; return FEAHIP_EINVAL; }
   c->linesearch_max = max_iterations;
   return FEAHIP_OK;
@@ -292,20 +323,20 @@ extern "C" int feahip_set_line_search(feahip_ctx *c, int max_iterations)
 
 extern "C" int feahip_set_row_shard(feahip_ctx *c, int rank, int nranks)
 {
-  CTX_GUARD(c);
+  CTX_GUARD_NOK(c);
   return install_shard(c, rank, nranks);
 }
 
 extern "C" int feahip_update_nodes_with_bc(feahip_ctx *c, double lambda)
 {
-  CTX_GUARD(c);
+  CTX_GUARD_NOK(c);
   c->state_valid = false;
   return launch_update_nodes_bc(c, lambda);
 }
 
 extern "C" int feahip_update_state(feahip_ctx *c, int *n_bad)
 {
-  CTX_GUARD(c);
+  CTX_GUARD_NOK(c);
   c->state_valid = false;
   if (n_bad) {
     FEA_HIP_CHECK(c, hipMemcpyAsync(&c->last_bad, c->d_flag + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -322,9 +353,12 @@ extern "C" int feahip_create_stiffness_and_residual(feahip_ctx *c) { CTX_GUARD(c
 extern "C" int feahip_stash_stiffness(feahip_ctx *c)
 {
   CTX_GUARD(c);
-  const size_t bytes = sizeof(double) * 9 * (size_t)c->nnzb;
-  if (!c->d_Kstash) FEA_HIP_CHECK(c, hipMalloc((void **)&c->d_Kstash, bytes ? bytes : 8));
-  FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_Kstash, c->d_K, bytes, hipMemcpyDeviceToDevice, c->stream));
+  const size_t bytes = sizeof(double) * 9 * (size_t)(c->kb1 - c->kb0);
+  if (!c->d_Kstash_base) {
+    FEA_HIP_CHECK(c, hipMalloc((void **)&c->d_Kstash_base, bytes ? bytes : 8));
+    c->d_Kstash = c->d_Kstash_base - (size_t)c->kb0 * 9;
+  }
+  FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_Kstash_base, c->d_K_base, bytes, hipMemcpyDeviceToDevice, c->stream));
   c->have_stash = true;
   c->stash_epoch = c->k_epoch;
   return FEAHIP_OK;
@@ -334,7 +368,7 @@ extern "C" int feahip_restore_stiffness(feahip_ctx *c)
 {
   CTX_GUARD(c);
   if (!c->have_stash) { c->err = "restore_stiffness before stash_stiffness"; return FEAHIP_ESTATE; }
-  FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_K, c->d_Kstash, sizeof(double) * 9 * (size_t)c->nnzb,
+  FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_K_base, c->d_Kstash_base, sizeof(double) * 9 * (size_t)(c->kb1 - c->kb0),
                                   hipMemcpyDeviceToDevice, c->stream));
   c->k_epoch = c->stash_epoch; c->k_bc = false;
   return FEAHIP_OK;
@@ -388,7 +422,7 @@ extern "C" int feahip_comm_unique_id(void *out, int cap) { return rccl_unique_id
 
 extern "C" int feahip_comm_init(feahip_ctx *c, int rank, int nranks, const void *unique_id)
 {
-  CTX_GUARD(c);
+  CTX_GUARD_NOK(c);
   if (!unique_id) return FEAHIP_EINVAL;
   int rc = install_shard(c, rank, nranks);
   if (rc) return rc;
@@ -497,7 +531,7 @@ extern "C" int feahip_shard_plan(int n_nodes, int n_elems, int npe, const int *e
 
 extern "C" int feahip_set_nodes(feahip_ctx *c, const double *nodes)
 {
-  CTX_GUARD(c);
+  CTX_GUARD_NOK(c);
   if (!nodes) return FEAHIP_EINVAL;
   std::vector<double> pad((size_t)c->N * 4, 0.0);
   for (int a = 0; a < c->N; ++a)
@@ -510,7 +544,7 @@ extern "C" int feahip_set_nodes(feahip_ctx *c, const double *nodes)
 
 extern "C" int feahip_get_nodes(feahip_ctx *c, double *nodes)
 {
-  CTX_GUARD(c);
+  CTX_GUARD_NOK(c);
   if (!nodes) return FEAHIP_EINVAL;
   std::vector<double> pad((size_t)c->N * 4);
   FEA_HIP_CHECK(c, hipMemcpyAsync(pad.data(), c->d_x, sizeof(double) * pad.size(), hipMemcpyDeviceToHost, c->stream));
@@ -571,6 +605,23 @@ extern "C" int feahip_get_stresses(feahip_ctx *c, double *S)
   return get_vec(c, c->d_S, S, (size_t)c->E * c->G * 9);
 }
 
+extern "C" int feahip_get_shape_gradients(feahip_ctx *c, double *grads, double *detj)
+{
+  CTX_GUARD(c);
+  if (!grads || !detj) return FEAHIP_EINVAL;
+  int rc = ensure_state(c);                                  // allocates F / sigma (the kernel writes them too)
+  if (rc) return rc;
+  const size_t ng = (size_t)c->E * c->G * 3 * c->npe, nd = (size_t)c->E * c->G;
+  double *dg = nullptr, *dd = nullptr;
+  FEA_HIP_CHECK(c, hipMalloc((void **)&dg, sizeof(double) * ng));
+  if (hipMalloc((void **)&dd, sizeof(double) * nd) != hipSuccess) { (void)hipFree(dg); c->err = "out of device memory"; return FEAHIP_ENOMEM; }
+  rc = launch_state_export(c, dg, dd);
+  if (!rc) rc = get_vec(c, dg, grads, ng);
+  if (!rc) rc = get_vec(c, dd, detj, nd);
+  (void)hipFree(dg); (void)hipFree(dd);
+  return rc;
+}
+
 extern "C" int feahip_matrix_nnz(feahip_ctx *c, long long *nnz)
 {
   if (!c || !nnz) return FEAHIP_EINVAL;
@@ -583,8 +634,8 @@ extern "C" int feahip_get_matrix_yale(feahip_ctx *c, int *offsets, int *indexes,
   CTX_GUARD(c);
   if (!offsets || !indexes || !values) return FEAHIP_EINVAL;
   if ((long long)c->nnzb * 9 > 0x7FFFFFFFLL) { c->err = "matrix too large for 32-bit Yale offsets"; return FEAHIP_EINVAL; }
-  std::vector<double> K((size_t)c->nnzb * 9);
-  int rc = get_vec(c, c->d_K, K.data(), K.size());
+  std::vector<double> K((size_t)c->nnzb * 9, 0.0);               // rows of other ranks read as zero
+  int rc = get_vec(c, c->d_K_base, K.data() + (size_t)c->kb0 * 9, (size_t)(c->kb1 - c->kb0) * 9);
   if (rc) return rc;
   int pos = 0;
   offsets[0] = 0;
@@ -642,12 +693,20 @@ extern "C" int feahip_time_kernel(feahip_ctx *c, int what, int warmup, int iters
   return FEAHIP_OK;
 }
 
+extern "C" int feahip_assembly_in_use(feahip_ctx *c, int *strategy)
+{
+  if (!c || !strategy) return FEAHIP_EINVAL;
+  *strategy = c->last_strategy;
+  return FEAHIP_OK;
+}
+
 extern "C" int feahip_sizes(feahip_ctx *c, long long *o)
 {
   if (!c || !o) return FEAHIP_EINVAL;
   o[0] = c->N; o[1] = c->E; o[2] = c->npe; o[3] = c->G; o[4] = c->nnzb; o[5] = c->nchunks;
   // bytes of the maps the default assembly kernel reads besides the algorithmic inputs
-  o[6] = c->have_visits ? c->visit_bytes + (long long)(c->N + 1) * 8
+  o[6] = c->have_gather ? c->gather_bytes
+       : c->have_visits ? c->visit_bytes + (long long)(c->N + 1) * 8
        : c->have_quad ? c->quad_bytes + (long long)(c->N + 1) * 8 : c->aux_bytes;
   o[7] = c->max_rowlen;
   return FEAHIP_OK;

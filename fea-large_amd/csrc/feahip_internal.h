@@ -51,6 +51,7 @@ struct feahip_ctx {
   int model = 0;
   double lambda = 0, mu = 0;
   int strategy = FEAHIP_ASM_AUTO;
+  int last_strategy = FEAHIP_ASM_AUTO;   // what the most recent assembly launch ran
 
   ElemTable table;
   ElemTable *d_table = nullptr;
@@ -62,8 +63,14 @@ struct feahip_ctx {
   // block-CSR pattern of K (built once; topology never changes)
   int *d_rowptr = nullptr;     // [N+1]
   int *d_colidx = nullptr;     // [nnzb]
-  double *d_K = nullptr;       // [nnzb][3][3]
-  double *d_Kstash = nullptr;  // modified-Newton copy (fea_solver.c:179)
+  // K holds the block rows this rank owns and nothing else: blocks [kb0, kb1) = rowptr[row0] .. rowptr[row1] (all of
+  // them for an unsharded context).  It is allocated on first use, for the shard installed by then, so a rank of a
+  // sharded run never holds the other ranks' rows (the reference keeps one row-wise store, fea_solver.c:444-448,
+  // and its modified-Newton copy, :179).  Kernels index by GLOBAL block number through d_K = d_K_base - 9 kb0.
+  double *d_K = nullptr;       // [nnzb][3][3], valid for blocks [kb0, kb1) only
+  double *d_Kstash = nullptr;  // modified-Newton copy (fea_solver.c:179), same window
+  double *d_K_base = nullptr, *d_Kstash_base = nullptr;   // the allocations
+  long long kb0 = 0, kb1 = 0;
   bool have_stash = false;
   // node -> element incidence (row-owner assembly)
   int *d_incptr = nullptr;     // [N+1]
@@ -78,7 +85,7 @@ struct feahip_ctx {
   uint16_t *d_pelem = nullptr, *d_pent = nullptr, *d_pbptr = nullptr;
   long long patch_bytes = 0;
   // LDS-staged visit assembly maps (linear tetrahedra)
-  bool have_visits = false;
+  bool have_visits = false, visits_failed = false;
   struct VisitDesc *d_vdesc = nullptr;
   int *d_vnode = nullptr;
   uint32_t *d_vrec = nullptr;
@@ -95,6 +102,7 @@ struct feahip_ctx {
   unsigned char *d_gmaps = nullptr;
   struct GatherLayout *gather_lay = nullptr;
   long long gather_bytes = 0;
+  double gather_evals_per_element = 0;   // element evaluations the gather chunks make per element this rank touches
   bool have_pairs = false;
   struct VisitDesc *d_pairdesc = nullptr;
   uint32_t *d_prec = nullptr;
@@ -238,24 +246,26 @@ int launch_assemble_quad(feahip_ctx *c, bool doF);
 #define FEA_G_THREADS 256
 #define FEA_G_MAX_ROWS 16
 #define FEA_G_MAX_NODES 128
-#define FEA_G_MAX_ELEMS 255           // 8-bit element index; one more record slot is kept all-zero
+#define FEA_G_MAX_ELEMS 239           // 8-bit record slot, slots come in sixteens and one stays all-zero
 #define FEA_G_REGW 4                  // contribution words a block thread keeps in registers (2 entries each)
 struct GatherHeader {                // 64 bytes, first thing in a chunk record
   int r0, r1, b0, nb;                // rows [r0, r1), blocks [b0, b0+nb) of the CSR
   int nnode, nelem, noffd, depth;    // depth: contribution words per block thread
   int nvthr, vdepth;                 // residual threads, visits per residual thread
-  int pad[6];
+  int ddepth;                        // diagonal-block words per lane of the last wave
+  int pad[5];
 };
 struct GatherLayout {                // the same for every chunk of a context
   int stride;                        // bytes per chunk record
-  int o_nodes, o_elems, o_bpos, o_rows, o_vlist, o_clist;   // byte offsets of the sections
+  int o_nodes, o_elems, o_bpos, o_rows, o_vlist, o_dlist, o_clist;   // byte offsets of the sections
   int max_nodes, max_elems, max_tile;                        // LDS tiles: coordinates, element records, K blocks
-  int max_tasks, max_depth, max_vthr, max_vdepth;            // largest chunk: block threads, contribution words, residual threads, visits
+  int max_tasks, max_depth, max_vthr, max_vdepth, max_ddepth;   // largest chunk: block threads, contribution words, residual threads, visits, diagonal words
 };
 struct HostGather {
   GatherLayout lay;
   std::vector<unsigned char> blob;   // nchunks records of lay.stride bytes
   std::vector<int> first_row;        // [nchunks+1]
+  long long total_evals = 0, distinct_elems = 0;   // element evaluations of all chunks; elements touching the rows
   int nchunks = 0;
   bool ok = false;
 };
@@ -277,12 +287,15 @@ int launch_assemble_visit(feahip_ctx *c, bool doK, bool doF, bool pipelined);
 // launchers (kernels_assemble.hip / kernels_patch.hip / kernels_solve.hip)
 int launch_assemble_patch(feahip_ctx *c, bool doF);
 int launch_assemble(feahip_ctx *c, bool doK, bool doF);
-int launch_state_export(feahip_ctx *c);
+int launch_state_export(feahip_ctx *c, double *d_grads = nullptr, double *d_detj = nullptr);
 int launch_apply_bc(feahip_ctx *c, double lambda);
 int launch_update_nodes_bc(feahip_ctx *c, double lambda);
 int ensure_generic_maps(feahip_ctx *c);
 int ensure_patches(feahip_ctx *c);
 int ensure_pairs(feahip_ctx *c);
+int ensure_k(feahip_ctx *c);
+void release_k(feahip_ctx *c);
+int ensure_visits(feahip_ctx *c);
 int dist_nodes_add_scaled(std::vector<feahip_ctx *> &R, double eta, bool exchange);
 int launch_update_nodes_solution(feahip_ctx *c, const double *d_u);
 int launch_spmv(feahip_ctx *c, const double *d_xv, double *d_yv);

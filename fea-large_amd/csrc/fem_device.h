@@ -21,6 +21,7 @@
 
 struct AsmArgs {
   int N, E, G, nchunks, chunk0, model;   // chunks [chunk0, chunk0+nchunks) are this launch's
+  int row0, row1;                        // block rows this rank owns (K holds no others)
   double lambda, mu;
   const ElemTable *tab;
   const int *conn;
@@ -35,6 +36,7 @@ struct AsmArgs {
   const int *diag;               // [N] diagonal block of every row
   int *bad;                      // counter of Gauss points with det J <= 0
   double *Fout, *Sout;           // state export
+  double *Gout, *Dout;           // shape gradients [E][G][3][npe] and det J [E][G] (null: not exported)
 };
 
 template <int NPE>

@@ -31,6 +31,7 @@
 #include "fem_device.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 struct GatherArgs {
   int chunk0, nchunks, model;
@@ -42,7 +43,13 @@ struct GatherArgs {
   double *K, *f;
   int *bad;
   unsigned long long *stamps;    // diagnostic build only: [chunk][8] s_memtime deltas
+  int ablate;                    // diagnostic build only: timing experiments (results meaningless)
 };
+#ifdef FEAHIP_DEBUG
+#define G_ABL(bit) (A.ablate & (bit))
+#else
+#define G_ABL(bit) 0
+#endif
 
 #ifdef FEAHIP_DEBUG
 #define G_STAMP(i) do { if (A.stamps) st[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -57,24 +64,28 @@ struct GatherArgs {
 #define GREC 26                  // doubles per element record (stiffness): g[4][3], t[4][3], vl, vm
 #define GREC_F 12                // residual only: s[4][3] = vol sigma g
 
-// Record layout (13 x 16 bytes; every vector read is one aligned ds_read_b128 + one ds_read_b64):
-//   pieces 0-3 (g_k.x, g_k.y)   4-5 (g_0.z .. g_3.z)   6-9 (t_k.x, t_k.y)   10-11 (t_0.z .. t_3.z)   12 (vl, vm)
+// Record layout (13 pieces of 16 bytes; every read of a record is one aligned ds_read_b128, and which LDS bank
+// slot a piece falls into is decided by the record's slot mod 16 -- gather.cpp places the elements accordingly):
+//   pieces 0-3 P_k = (g_k.x, g_k.y)   4-7 Q_k = (t_k.x, t_k.y)   8-11 Z_k = (g_k.z, t_k.z)   12 (vl, vm)
 // residual-only record (6 pieces): 0-3 (s_k.x, s_k.y), 4-5 (s_0.z .. s_3.z), s = vol sigma g
 //
-// one contribution (element el, local row node la, local column node lb) to the thread's block
-// (an empty slot of the list points at the all-zero record: no branch)
-__device__ __forceinline__ void g_consume(const double *sT, unsigned w, double (&acc)[9])
+// one contribution (element slot, local row node la, local column node lb) to the thread's block
+// (an empty slot of the list points at an all-zero record: no branch)
+struct GRead { double2 pa, za, pb, qb, zb, vv; };
+__device__ __forceinline__ GRead g_fetch(const double *sT, unsigned w)
 {
-  const double *T = sT + (w & 255u) * GREC;
+  const double2 *T = reinterpret_cast<const double2 *>(sT + (w & 255u) * GREC);
   const int la = (w >> 8) & 3, lb = (w >> 10) & 3;
-  const double2 pa = *reinterpret_cast<const double2 *>(T + 2 * la);
-  const double2 pb = *reinterpret_cast<const double2 *>(T + 2 * lb);
-  const double2 qb = *reinterpret_cast<const double2 *>(T + 12 + 2 * lb);
-  const double2 vv = *reinterpret_cast<const double2 *>(T + 24);
-  const double ga0 = pa.x, ga1 = pa.y, ga2 = T[8 + la];
-  const double gb0 = pb.x, gb1 = pb.y, gb2 = T[8 + lb];
-  const double tb0 = qb.x, tb1 = qb.y, tb2 = T[20 + lb];
-  const double vl = vv.x, vm = vv.y;
+  GRead r;
+  r.pa = T[la]; r.za = T[8 + la]; r.pb = T[lb]; r.qb = T[4 + lb]; r.zb = T[8 + lb]; r.vv = T[12];
+  return r;
+}
+__device__ __forceinline__ void g_apply(const GRead &r, double (&acc)[9])
+{
+  const double ga0 = r.pa.x, ga1 = r.pa.y, ga2 = r.za.x;
+  const double gb0 = r.pb.x, gb1 = r.pb.y, gb2 = r.zb.x;
+  const double tb0 = r.qb.x, tb1 = r.qb.y, tb2 = r.zb.y;
+  const double vl = r.vv.x, vm = r.vv.y;
   const double h0 = vl * gb0, h1 = vl * gb1, h2 = vl * gb2;
   const double m0 = vm * gb0, m1 = vm * gb1, m2 = vm * gb2;
   const double d = ga0 * tb0 + ga1 * tb1 + ga2 * tb2;
@@ -83,6 +94,40 @@ __device__ __forceinline__ void g_consume(const double *sT, unsigned w, double (
   acc[3] = fma(ga1, h0, fma(ga0, m1, acc[3])); acc[4] = fma(ga1, h1, fma(ga1, m1, acc[4])); acc[5] = fma(ga1, h2, fma(ga2, m1, acc[5]));
   acc[6] = fma(ga2, h0, fma(ga0, m2, acc[6])); acc[7] = fma(ga2, h1, fma(ga1, m2, acc[7])); acc[8] = fma(ga2, h2, fma(ga2, m2, acc[8]));
 }
+__device__ __forceinline__ void g_consume(const double *sT, unsigned w, double (&acc)[9])
+{
+  g_apply(g_fetch(sT, w), acc);
+}
+__device__ __forceinline__ void g_apply_cheap(const GRead &r, double (&acc)[9])
+{
+  acc[0] += r.pa.x; acc[1] += r.za.x; acc[2] += r.pb.x; acc[3] += r.qb.x; acc[4] += r.zb.x; acc[5] += r.vv.x;
+}
+__device__ __forceinline__ GRead g_fetch_cheap(const double *sT, unsigned w)
+{
+  GRead r; const double v = (double)w;
+  r.pa = make_double2(v, v); r.za = r.pa; r.pb = r.pa; r.qb = r.pa; r.zb = r.pa; r.vv = r.pa;
+  return r;
+}
+
+// one visit (element slot, local node la) to a row's diagonal block: K_aa^e = (vl + vm) g_a (x) g_a + (g_a . t_a) I,
+// symmetric: a = { 00, 01, 02, 11, 12, 22 }
+template <bool DOF>
+__device__ __forceinline__ void g_consume_diag(const double *sT, unsigned w, double (&a)[6], double (&fa)[3])
+{
+  const double2 *T = reinterpret_cast<const double2 *>(sT + (w & 255u) * GREC);
+  const int la = (w >> 8) & 3;
+  const double2 pa = T[la], qa = T[4 + la], za = T[8 + la], vv = T[12];
+  const double s = vv.x + vv.y;
+  const double d = pa.x * qa.x + pa.y * qa.y + za.x * za.y;
+  const double h0 = s * pa.x, h1 = s * pa.y, h2 = s * za.x;
+  a[0] += fma(h0, pa.x, d); a[1] = fma(h0, pa.y, a[1]); a[2] = fma(h0, za.x, a[2]);
+  a[3] += fma(h1, pa.y, d); a[4] = fma(h1, za.x, a[4]); a[5] += fma(h2, za.x, d);
+  if (DOF) {
+    // the same visits carry the row's residual: -vol sigma g_a = -(t_a - vm g_a), with the product rounded exactly
+    // as it was when t_a was formed (no fused multiply-add on either side): a stress-free state gives f = 0 to the bit
+    fa[0] -= __dsub_rn(qa.x, __dmul_rn(vv.y, pa.x)); fa[1] -= __dsub_rn(qa.y, __dmul_rn(vv.y, pa.y)); fa[2] -= __dsub_rn(za.y, __dmul_rn(vv.y, za.x));
+  }
+}
 
 // residual contribution of one (element, local node) visit: -vol sigma g_a (fea_solver.c:1096-1109)
 template <bool DOK>
@@ -90,11 +135,10 @@ __device__ __forceinline__ void g_visit(const double *sT, unsigned w, double (&f
 {
   const int la = (w >> 8) & 3;
   if (DOK) {
-    const double *T = sT + (w & 255u) * GREC;
-    const double2 pa = *reinterpret_cast<const double2 *>(T + 2 * la);
-    const double2 qa = *reinterpret_cast<const double2 *>(T + 12 + 2 * la);
-    const double vm = T[25];
-    fa[0] -= qa.x - vm * pa.x; fa[1] -= qa.y - vm * pa.y; fa[2] -= T[20 + la] - vm * T[8 + la];
+    const double2 *T = reinterpret_cast<const double2 *>(sT + (w & 255u) * GREC);
+    const double2 pa = T[la], qa = T[4 + la], za = T[8 + la];
+    const double vm = T[12].y;
+    fa[0] -= qa.x - vm * pa.x; fa[1] -= qa.y - vm * pa.y; fa[2] -= za.y - vm * za.x;
   } else {
     const double *T = sT + (w & 255u) * GREC_F;
     const double2 pa = *reinterpret_cast<const double2 *>(T + 2 * la);
@@ -109,12 +153,12 @@ __device__ __forceinline__ void g_store_record(double *dst, const double *R)
   double2 *o = reinterpret_cast<double2 *>(dst);
 #pragma unroll
   for (int k = 0; k < 4; ++k) o[k] = make_double2(R[3 * k], R[3 * k + 1]);
-  o[4] = make_double2(R[2], R[5]); o[5] = make_double2(R[8], R[11]);
   if (DOK) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[6 + k] = make_double2(R[12 + 3 * k], R[12 + 3 * k + 1]);
-    o[10] = make_double2(R[14], R[17]); o[11] = make_double2(R[20], R[23]);
+    for (int k = 0; k < 4; ++k) { o[4 + k] = make_double2(R[12 + 3 * k], R[12 + 3 * k + 1]); o[8 + k] = make_double2(R[3 * k + 2], R[12 + 3 * k + 2]); }
     o[12] = make_double2(R[24], R[25]);
+  } else {
+    o[4] = make_double2(R[2], R[5]); o[5] = make_double2(R[8], R[11]);
   }
 }
 
@@ -124,7 +168,7 @@ __device__ __forceinline__ void g_store_record(double *dst, const double *R)
 //   Neo-Hookean: B = F F' = (F^-T F^-1)^-1 by the adjugate of the symmetric C = Fi'Fi, J = 1/det Fi:
 //     vol sigma = vol mu J adj(C) - vol (mu - lambda ln J)/J I,  l1 = lambda/J, m1 = (mu - lambda ln J)/J
 //                                                                                        fea_model.c:79-107,129-148
-//   t_k = vol (m1 g_k + sigma g_k), t_0 = -(t_1 + t_2 + t_3)
+//   t_k = vol (m1 g_k + sigma g_k)
 // R = { g[4][3], t[4][3], vol l1, vol m1 } (DOK) or { vol sigma g [4][3] } (residual only).
 // Returns det J (its sign and zero test are the caller's business).
 template <bool DOK>
@@ -182,13 +226,13 @@ __device__ __forceinline__ double lintet_record_nh(const double (&x)[4][3], cons
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int i = 0; i < 3; ++i) R[b * 3 + i] = g[b][i];
+    // t_b = round(vm g_b) + vol sigma g_b, every node alike and without fused multiply-add, so that the residual
+    // -(t_a - round(vm g_a)) of a stress-free state is zero to the bit (g_consume_diag)
 #pragma unroll
-    for (int b = 1; b < 4; ++b)
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int i = 0; i < 3; ++i)
-        R[12 + b * 3 + i] = fma(vm, g[b][i], S[i][0] * g[b][0] + S[i][1] * g[b][1] + S[i][2] * g[b][2]);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) R[12 + i] = -((R[15 + i] + R[18 + i]) + R[21 + i]);
+        R[12 + b * 3 + i] = __dadd_rn(__dmul_rn(vm, g[b][i]), S[i][0] * g[b][0] + S[i][1] * g[b][1] + S[i][2] * g[b][2]);
     R[24] = (vol * lambda) * detFi;                   // vol lambda/J
     R[25] = vm;
   } else {
@@ -215,31 +259,17 @@ __device__ __forceinline__ double lintet_record_any(const double (&xe)[4][3], co
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const double sg = s.vol * (s.sig[i][0] * s.g[b][0] + s.sig[i][1] * s.g[b][1] + s.sig[i][2] * s.g[b][2]);
-      if (DOK) { R[b * 3 + i] = s.g[b][i]; R[12 + b * 3 + i] = fma(vm, s.g[b][i], sg); }
+      if (DOK) { R[b * 3 + i] = s.g[b][i]; R[12 + b * 3 + i] = __dadd_rn(__dmul_rn(vm, s.g[b][i]), sg); }
       else R[b * 3 + i] = sg;
     }
   if (DOK) { R[24] = s.vol * s.l1; R[25] = vm; }
   return s.detJ;
 }
 
-// LDS-DMA load of 16 bytes per active lane: lane l's bytes land at lds_base + 16 l.  Inline asm on purpose: the
-// compiler drains a __builtin_amdgcn_global_load_lds at once (it waits before the next instruction that reuses
-// the address registers); an asm load is outside its bookkeeping and is waited for where the pipeline wants it.
-__device__ __forceinline__ void g_dma16(const void *gsrc, unsigned lds_base)
-{
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
-}
-__device__ __forceinline__ unsigned g_lds_addr(const void *p)
-{
-  return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
-}
 // workgroup barrier that orders LDS only: __syncthreads() would also drain every global load and store in flight
 // (s_waitcnt vmcnt(0)), i.e. the prefetches of the next chunk and the row stores of the previous one
 #define G_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); \
                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
-#define G_VMEM_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 typedef int g_v8i __attribute__((ext_vector_type(8)));
 typedef int g_v4i __attribute__((ext_vector_type(4)));
@@ -247,8 +277,10 @@ typedef int g_v4i __attribute__((ext_vector_type(4)));
 // what a thread holds of one chunk's map record
 struct GMaps {
   unsigned eids, tpos, cw[FEA_G_REGW], vw[2];
-  int kb, ke, kd, vb, ve;
+  int kd, vb, ve;
 };
+
+#define G_TASK_THREADS 192           // block and residual threads: waves 0-2; wave 3 sums the diagonal blocks
 
 template <bool DOK, bool DOF>
 __device__ __forceinline__ void g_load_maps(const GatherLayout &lay, const unsigned char *rec, int t, GMaps &m)
@@ -256,7 +288,7 @@ __device__ __forceinline__ void g_load_maps(const GatherLayout &lay, const unsig
   // Loads from inside the record (always in bounds), masked by what the LARGEST chunk of the mesh needs (known
   // without the header of this chunk, so none of them waits for it); a thread never uses a word it does not own.
   const unsigned short *rows = reinterpret_cast<const unsigned short *>(rec + lay.o_rows);
-  m.eids = 0; m.tpos = 0; m.kb = m.ke = m.kd = m.vb = m.ve = 0;
+  m.eids = 0xFFFFFFFFu; m.tpos = 0; m.kd = m.vb = m.ve = 0;
 #pragma unroll
   for (int k = 0; k < FEA_G_REGW; ++k) m.cw[k] = 0;
   m.vw[0] = m.vw[1] = 0;
@@ -267,37 +299,37 @@ __device__ __forceinline__ void g_load_maps(const GatherLayout &lay, const unsig
     for (int k = 0; k < FEA_G_REGW; ++k)
       if (k < lay.max_depth) m.cw[k] = reinterpret_cast<const unsigned *>(rec + lay.o_clist)[k * FEA_G_THREADS + t];
   }
-  if (DOF && t < ((lay.max_vthr + 63) & ~63)) {
+  if (DOK && t >= G_TASK_THREADS) {                   // wave 3: four lanes per row, the visits of its diagonal block
+    const int l = t - G_TASK_THREADS;
+    m.kd = rows[G_RD + (l >> 2)];
+#pragma unroll
+    for (int k = 0; k < FEA_G_REGW; ++k)
+      if (k < lay.max_ddepth) m.cw[k] = reinterpret_cast<const unsigned *>(rec + lay.o_dlist)[k * 64 + l];
+  }
+  if (!DOK && t < ((lay.max_vthr + 63) & ~63)) {
 #pragma unroll
     for (int v = 0; v < 2; ++v)
       if (v < lay.max_vdepth) m.vw[v] = reinterpret_cast<const unsigned short *>(rec + lay.o_vlist)[v * FEA_G_THREADS + t];
   }
-  if (DOK) {
-    const int dr = min(t / 9, FEA_G_MAX_ROWS - 1);
-    m.kb = rows[G_RS + dr]; m.ke = rows[G_RS + dr + 1]; m.kd = rows[G_RD + dr];
-  }
-  if (DOF) {
-    const int ft = DOK ? max(t - 192, 0) : t;
-    const int fr = min(ft / 3, FEA_G_MAX_ROWS - 1);
+  if (!DOK) {
+    const int fr = min(t / 3, FEA_G_MAX_ROWS - 1);
     m.vb = rows[G_VF + fr]; m.ve = rows[G_VF + fr + 1];
   }
 }
 
 // Persistent form: a workgroup walks a run of consecutive chunks and keeps the next chunk's loads in flight under
 // the current chunk's arithmetic --
-//   * the map words of chunk i+1 (and the node ids of chunk i+2) are requested while chunk i is in its gather phase;
-//   * as soon as the state phase of chunk i is over (the coordinate tile is dead) the coordinates of chunk i+1 go
-//     HBM -> LDS by LDS-DMA (no registers held) and land under the gather / tile / diagonal phases;
+//   * the map words and the node coordinates of chunk i+1 (and the node ids of chunk i+2) are requested before the
+//     state phase of chunk i and sit in registers; the coordinates move into the LDS tile after chunk i's gather
+//     phase (the tile is dead from the end of the state phase), a whole state + gather phase after their request;
 //   * the finished rows of chunk i are stored last and nobody waits for them.
 template <bool DOK, bool DOF, bool NH>
 __global__ __launch_bounds__(FEA_G_THREADS, 3)
 void k_assemble_gather(GatherArgs A, int run_len)
 {
   extern __shared__ double2 g_smem[];
-  // coordinates: per 64 nodes four lane-linear 1 KB pieces as the LDS-DMA writes them: (x0,x1) (x2,-) (X0,X1) (X2,-)
-  double2 *sC = g_smem;
-  const int ncw = (A.lay.max_nodes + 63) >> 6;               // waves that carry coordinates
-  double *sT = reinterpret_cast<double *>(g_smem + ncw * 256);   // element records; later the K tile and the residual partials
+  double2 *sC = g_smem;                                       // per node slot 3 x 16 bytes: (x0,x1) (x2,X0) (X1,X2)
+  double *sT = reinterpret_cast<double *>(g_smem + A.lay.max_nodes * 3);   // element records; later the K tile and the residual partials
   const int t = threadIdx.x;
 #ifdef FEAHIP_DEBUG
   unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -313,24 +345,23 @@ void k_assemble_gather(GatherArgs A, int run_len)
   constexpr int REC = DOK ? GREC : GREC_F;
   const size_t stride = (size_t)A.lay.stride;
   const unsigned char *rec = A.maps + (size_t)(A.chunk0 + chunk) * stride;
-  const bool cw_lane = t < ncw * 64;
-  const int cwave = t >> 6;
+  const bool node_lane = t < A.lay.max_nodes;
 
   // ---- prologue: maps and coordinates of the first chunk, nothing to hide behind
   GMaps mn;                                                   // "next": the chunk about to be worked on
   g_load_maps<DOK, DOF>(A.lay, rec, t, mn);
   GatherHeader hn = *reinterpret_cast<const GatherHeader *>(rec);
-  int node1 = reinterpret_cast<const int *>(rec + A.lay.o_nodes)[t & (FEA_G_MAX_NODES - 1)];       // nodes of the chunk to DMA next
-  if (cw_lane) {
+  int node1 = reinterpret_cast<const int *>(rec + A.lay.o_nodes)[t & (FEA_G_MAX_NODES - 1)];       // node slot t of the chunk whose coordinates are loaded next
+  if (node_lane) {
     const double *gx = A.x + (size_t)node1 * 4, *gX = A.X0 + (size_t)node1 * 4;
-    const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)g_lds_addr(sC + cwave * 256));
-    g_dma16(gx, base); g_dma16(gx + 2, base + 1024); g_dma16(gX, base + 2048); g_dma16(gX + 2, base + 3072);
+    const double2 a0 = *reinterpret_cast<const double2 *>(gx), a1 = *reinterpret_cast<const double2 *>(gx + 2);
+    const double2 c0 = *reinterpret_cast<const double2 *>(gX), c1 = *reinterpret_cast<const double2 *>(gX + 2);
+    sC[t * 3] = a0; sC[t * 3 + 1] = make_double2(a1.x, c0.x); sC[t * 3 + 2] = make_double2(c0.y, c1.x);
   }
   {
     const int cn = min(chunk + 1, cend - 1);
     node1 = reinterpret_cast<const int *>(A.maps + (size_t)(A.chunk0 + cn) * stride + A.lay.o_nodes)[t & (FEA_G_MAX_NODES - 1)];
   }
-  G_VMEM_DRAIN();
   G_BARRIER();
 
   for (;;) {
@@ -342,21 +373,38 @@ void k_assemble_gather(GatherArgs A, int run_len)
     const int nrows = h.r1 - h.r0;
     rec = A.maps + (size_t)(A.chunk0 + chunk) * stride;
 
+    // ---- next chunk's loads, a whole state + gather phase ahead of their first use: header, map words, node
+    // coordinates (by the node ids requested one chunk earlier), and the node ids of the chunk after it.
+    // Clamped indices instead of branches (a load under a branch is waited for at the join).
+    double2 ca0, ca1, cc0, cc1;
+    {
+      const int c1 = min(chunk + 1, cend - 1), c2 = min(chunk + 2, cend - 1);
+      const unsigned char *rec1 = A.maps + (size_t)(A.chunk0 + c1) * stride;
+      asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20" : "=s"(h8), "=s"(h4) : "s"(rec1) : "memory");
+      g_load_maps<DOK, DOF>(A.lay, rec1, t, mn);
+      const size_t n1 = (size_t)(node_lane ? node1 : 0);
+      ca0 = *reinterpret_cast<const double2 *>(A.x + n1 * 4); ca1 = *reinterpret_cast<const double2 *>(A.x + n1 * 4 + 2);
+      cc0 = *reinterpret_cast<const double2 *>(A.X0 + n1 * 4); cc1 = *reinterpret_cast<const double2 *>(A.X0 + n1 * 4 + 2);
+      node1 = reinterpret_cast<const int *>(A.maps + (size_t)(A.chunk0 + c2) * stride + A.lay.o_nodes)[t & (FEA_G_MAX_NODES - 1)];
+    }
+
     // ---- phase 1: one state evaluation per element of the chunk
-    if (t < h.nelem) {
+    if (t < h.nelem && m.eids != 0xFFFFFFFFu) {
       const unsigned eids = m.eids;
       const int nd[4] = {(int)(eids & 255u), (int)((eids >> 8) & 255u), (int)((eids >> 16) & 255u), (int)(eids >> 24)};
       double xe[4][3], Xe[4][3];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const double2 *cc = sC + (nd[k] >> 6) * 256 + (nd[k] & 63);
-        const double2 p0 = cc[0], p2 = cc[128];
-        xe[k][0] = p0.x; xe[k][1] = p0.y; xe[k][2] = cc[64].x;
-        Xe[k][0] = p2.x; Xe[k][1] = p2.y; Xe[k][2] = cc[192].x;
+        const double2 *cc = sC + nd[k] * 3;                 // 16-byte reads: the bank slot follows the node slot mod 16
+        const double2 p0 = cc[0], p1 = cc[1], p2 = cc[2];
+        xe[k][0] = p0.x; xe[k][1] = p0.y; xe[k][2] = p1.x;
+        Xe[k][0] = p1.y; Xe[k][1] = p2.x; Xe[k][2] = p2.y;
       }
       double R[REC];
-      const double detJ = NH ? lintet_record_nh<DOK>(xe, Xe, A.tab->w[0], A.lambda, A.mu, R)
-                             : lintet_record_any<DOK>(xe, Xe, A.tab, A.model, A.lambda, A.mu, R);
+      double detJ;
+      if (G_ABL(8)) { detJ = 1.0; for (int q = 0; q < REC; ++q) R[q] = xe[q & 3][q % 3] + Xe[(q >> 2) & 3][q % 3]; }
+      else detJ = NH ? lintet_record_nh<DOK>(xe, Xe, A.tab->w[0], A.lambda, A.mu, R)
+                     : lintet_record_any<DOK>(xe, Xe, A.tab, A.model, A.lambda, A.mu, R);
       if (!(detJ > 0.0)) {                             // rare, kept off the fast path
         if (DOK) {                                     // counted by the chunk that owns its lowest-numbered node
           const int *gn = reinterpret_cast<const int *>(rec + A.lay.o_nodes);
@@ -368,8 +416,8 @@ void k_assemble_gather(GatherArgs A, int run_len)
           for (int q = 0; q < REC; ++q) R[q] = 0.0;
         }
       }
-      g_store_record<DOK>(sT + t * REC, R);
-    } else if (t == h.nelem) {                         // the record empty list slots point at
+      if (!G_ABL(1)) g_store_record<DOK>(sT + t * REC, R); else sT[t * REC] = R[0] + R[25 % REC];
+    } else if (t < h.nelem) {                          // unused slot: the all-zero record empty list slots point at
       double2 *o = reinterpret_cast<double2 *>(sT + t * REC);
 #pragma unroll
       for (int q = 0; q < REC / 2; ++q) o[q] = make_double2(0.0, 0.0);
@@ -377,38 +425,40 @@ void k_assemble_gather(GatherArgs A, int run_len)
     G_BARRIER();                                       // records visible; the coordinate tile is dead
     G_STAMP(1);
 
-    // ---- next chunk's loads: coordinates HBM -> LDS, map words and header into the "next" registers, node ids
-    // of the chunk after it.  Clamped indices instead of branches (a load under a branch is waited for at the join).
-    {
-      const int c1 = min(chunk + 1, cend - 1), c2 = min(chunk + 2, cend - 1);
-      const unsigned char *rec1 = A.maps + (size_t)(A.chunk0 + c1) * stride;
-      if (more && cw_lane) {
-        const double *gx = A.x + (size_t)node1 * 4, *gX = A.X0 + (size_t)node1 * 4;
-        const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)g_lds_addr(sC + cwave * 256));
-        g_dma16(gx, base); g_dma16(gx + 2, base + 1024); g_dma16(gX, base + 2048); g_dma16(gX + 2, base + 3072);
-      }
-      asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20" : "=s"(h8), "=s"(h4) : "s"(rec1) : "memory");
-      g_load_maps<DOK, DOF>(A.lay, rec1, t, mn);
-      node1 = reinterpret_cast<const int *>(A.maps + (size_t)(A.chunk0 + c2) * stride + A.lay.o_nodes)[t & (FEA_G_MAX_NODES - 1)];
-    }
-
     // ---- phase 2: block sums and residual partials, out of the records
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (DOK && t < h.noffd) {
+      // the reads of the next contribution are in flight while the current one is summed; a list of n words is
+      // walked as 2n entries whatever it holds (empty entries read the all-zero record)
+#define G_FETCH(w) (G_ABL(4) ? g_fetch_cheap(sT, w) : g_fetch(sT, w))
+#define G_APPLY(r) do { if (G_ABL(2)) g_apply_cheap(r, acc); else g_apply(r, acc); } while (0)
 #pragma unroll
       for (int k = 0; k < FEA_G_REGW; ++k)
-        if (k < h.depth) { g_consume(sT, m.cw[k] & 0xFFFFu, acc); g_consume(sT, m.cw[k] >> 16, acc); }
+        if (k < h.depth) { { const GRead r = G_FETCH(m.cw[k] & 0xFFFFu); G_APPLY(r); } { const GRead r = G_FETCH(m.cw[k] >> 16); G_APPLY(r); } }
       for (int k = FEA_G_REGW; k < h.depth; ++k) {          // blocks with more than 8 contributions (unstructured meshes)
         const unsigned w = reinterpret_cast<const unsigned *>(rec + A.lay.o_clist)[k * FEA_G_THREADS + t];
         g_consume(sT, w & 0xFFFFu, acc); g_consume(sT, w >> 16, acc);
       }
     }
+    double dg[6] = {0, 0, 0, 0, 0, 0};
     double fa[3] = {0, 0, 0};
-    if (DOF && t < h.nvthr) {
+    if (DOK && t >= G_TASK_THREADS && t - G_TASK_THREADS < 4 * nrows) {
+#pragma unroll
+      for (int k = 0; k < FEA_G_REGW; ++k)
+        if (k < h.ddepth) { g_consume_diag<DOF>(sT, m.cw[k] & 0xFFFFu, dg, fa); g_consume_diag<DOF>(sT, m.cw[k] >> 16, dg, fa); }
+      for (int k = FEA_G_REGW; k < h.ddepth; ++k) {        // nodes with more than 32 elements around them
+        const unsigned w = reinterpret_cast<const unsigned *>(rec + A.lay.o_dlist)[k * 64 + t - G_TASK_THREADS];
+        g_consume_diag<DOF>(sT, w & 0xFFFFu, dg, fa); g_consume_diag<DOF>(sT, w >> 16, dg, fa);
+      }
+    }
+    if (!DOK && t < h.nvthr) {                         // residual alone: slices of a row's visits on every wave
       g_visit<DOK>(sT, m.vw[0], fa);
       if (h.vdepth > 1) g_visit<DOK>(sT, m.vw[1], fa);
       for (int v = 2; v < h.vdepth; ++v)
         g_visit<DOK>(sT, reinterpret_cast<const unsigned short *>(rec + A.lay.o_vlist)[v * FEA_G_THREADS + t], fa);
+    }
+    if (more && node_lane) {                           // next chunk's coordinates: the tile has been dead since the state phase
+      sC[t * 3] = ca0; sC[t * 3 + 1] = make_double2(ca1.x, cc0.x); sC[t * 3 + 2] = make_double2(cc0.y, cc1.x);
     }
     G_STAMP(2);
     G_BARRIER();                                       // the records are dead: their space becomes the tile
@@ -419,7 +469,7 @@ void k_assemble_gather(GatherArgs A, int run_len)
     const int odd = h.b0 & 1;
     double *sK = sT + odd;
     double *sF = DOK ? sT + ((A.lay.max_tile * 9 + 3) & ~1) : sT;
-    if (DOK && t < h.noffd) {
+    if (DOK && t < h.noffd && !G_ABL(16)) {
       const int bpos = (int)(m.tpos & 0xFFFFu), mpos = (int)(m.tpos >> 16);
 #pragma unroll
       for (int q = 0; q < 9; ++q) sK[bpos * 9 + q] = acc[q];
@@ -430,53 +480,52 @@ void k_assemble_gather(GatherArgs A, int run_len)
           for (int j = 0; j < 3; ++j) sK[mpos * 9 + 3 * j + i] = acc[3 * i + j];
       }
     }
-    if (DOF && t < h.nvthr) { sF[t * 3] = fa[0]; sF[t * 3 + 1] = fa[1]; sF[t * 3 + 2] = fa[2]; }
+    if (DOK && t >= G_TASK_THREADS) {                  // the four partial sums of a row's diagonal block meet in its first lane
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { dg[q] += __shfl_xor(dg[q], 1); dg[q] += __shfl_xor(dg[q], 2); }
+      if (DOF) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { fa[q] += __shfl_xor(fa[q], 1); fa[q] += __shfl_xor(fa[q], 2); }
+      }
+      if ((t & 3) == 0 && t - G_TASK_THREADS < 4 * nrows) {
+        double *o = sK + m.kd * 9;
+        o[0] = dg[0]; o[1] = dg[1]; o[2] = dg[2]; o[3] = dg[1]; o[4] = dg[3]; o[5] = dg[4]; o[6] = dg[2]; o[7] = dg[4]; o[8] = dg[5];
+        if (DOF) {
+          double *fo = A.f + (size_t)(h.r0 + ((t - G_TASK_THREADS) >> 2)) * 3;
+          fo[0] = fa[0]; fo[1] = fa[1]; fo[2] = fa[2];
+        }
+      }
+    }
+    if (!DOK && t < h.nvthr) { sF[t * 3] = fa[0]; sF[t * 3 + 1] = fa[1]; sF[t * 3 + 2] = fa[2]; }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(h8), "+s"(h4) : : "memory");     // and so has its header
+    hn.r0 = h8[0]; hn.r1 = h8[1]; hn.b0 = h8[2]; hn.nb = h8[3]; hn.nnode = h8[4]; hn.nelem = h8[5]; hn.noffd = h8[6]; hn.depth = h8[7];
+    hn.nvthr = h4[0]; hn.vdepth = h4[1]; hn.ddepth = h4[2];
     G_BARRIER();
     G_STAMP(4);
-
-    // ---- phase 3: K_aa = -sum_{b != a} K_ab; f_a = sum of the row's partials
-    {
-      const int dr = t / 9, dq = t - 9 * dr;
-      if (DOK && dr < nrows) {
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        const int kd = m.kd, ke = m.ke;
-        int k = m.kb;
-        for (; k + 3 < ke; k += 4) {
-          a0 += (k == kd) ? 0.0 : sK[k * 9 + dq]; a1 += (k + 1 == kd) ? 0.0 : sK[(k + 1) * 9 + dq];
-          a2 += (k + 2 == kd) ? 0.0 : sK[(k + 2) * 9 + dq]; a3 += (k + 3 == kd) ? 0.0 : sK[(k + 3) * 9 + dq];
-        }
-        for (; k < ke; ++k) a0 += (k == kd) ? 0.0 : sK[k * 9 + dq];
-        sK[kd * 9 + dq] = -((a0 + a1) + (a2 + a3));
-      }
-      const int ft = DOK ? t - 192 : t;                // wave 3 sums the residual while waves 0-2 sum diagonals
+    if (!DOK) {                                        // f_a = sum of the row's partials
+      const int ft = t;
       const int fr = ft / 3, fi = ft - 3 * fr;
-      if (DOF && ft >= 0 && fr < nrows) {
+      if (fr < nrows) {
         double a = 0;
         for (int k = m.vb; k < m.ve; ++k) a += sF[k * 3 + fi];
         A.f[(size_t)(h.r0 + fr) * 3 + fi] = a;
       }
     }
-    // the next chunk's coordinates and map words have had the whole gather phase to arrive: wait for them here,
-    // BEFORE this chunk's row stores are issued, so that nothing ever waits for a store
-    G_VMEM_DRAIN();
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(h8), "+s"(h4) : : "memory");     // and so has its header
-    hn.r0 = h8[0]; hn.r1 = h8[1]; hn.b0 = h8[2]; hn.nb = h8[3]; hn.nnode = h8[4]; hn.nelem = h8[5]; hn.noffd = h8[6]; hn.depth = h8[7];
-    hn.nvthr = h4[0]; hn.vdepth = h4[1];
-    G_BARRIER();
     G_STAMP(5);
     if (DOK) {
-      // ---- phase 4: stream the finished rows out, 16-byte LDS reads and HBM stores
+      // ---- phase 3: stream the finished rows out, 16-byte LDS reads and HBM stores
       double *Kd = A.K + (size_t)h.b0 * 9;
       const int total = h.nb * 9;
       if (odd && t == 0) Kd[0] = sK[0];
       const int npair = (total - odd) >> 1;
       for (int j = t; j < npair; j += FEA_G_THREADS) {
         const int p = odd + 2 * j;
+        if (G_ABL(32) && j >= 64) break;               // timing experiment: one 1 KB store per chunk instead of all rows
         *reinterpret_cast<double2 *>(Kd + p) = *reinterpret_cast<const double2 *>(sK + p);
       }
       if (((total - odd) & 1) && t == 0) Kd[total - 1] = sK[total - 1];
-      G_BARRIER();                                     // the tile is free again (LDS reads done), the DMA'd coordinates visible
     }
+    G_BARRIER();                                       // the tile is free again (its reads are done)
     G_STAMP(6);
 #ifdef FEAHIP_DEBUG
     if (A.stamps) for (int i = 0; i < 6; ++i) sa[i] += st[i + 1] - st[i];
@@ -507,20 +556,35 @@ int ensure_gather(feahip_ctx *c)
   c->ngchunks = hg.nchunks;
   c->gather_row0 = c->row0; c->gather_row1 = c->row1;
   c->gather_bytes = (long long)hg.blob.size();
+  c->gather_evals_per_element = hg.distinct_elems ? (double)hg.total_evals / (double)hg.distinct_elems : 0.0;
   c->have_gather = true;
   return FEAHIP_OK;
 }
+
+#ifdef FEAHIP_DEBUG
+// diagnostic build only: one chunk's map record and the layout, for the host-side LDS bank model (dbg/lds_model.py)
+extern "C" int feahip_debug_gather_record(feahip_ctx *c, int chunk, int *layout_ints, unsigned char *record)
+{
+  int rc = ensure_gather(c);
+  if (rc || !c->have_gather) return FEAHIP_ESTATE;
+  if (chunk < 0) chunk = c->ngchunks / 2;
+  memcpy(layout_ints, c->gather_lay, sizeof(GatherLayout));
+  if (record) (void)hipMemcpy(record, c->d_gmaps + (size_t)chunk * c->gather_lay->stride, c->gather_lay->stride, hipMemcpyDeviceToHost);
+  return (int)(sizeof(GatherLayout) / sizeof(int));
+}
+#endif
 
 int launch_assemble_gather(feahip_ctx *c, bool doK, bool doF)
 {
   GatherArgs A;
   A.chunk0 = 0; A.nchunks = c->ngchunks; A.model = c->model; A.lambda = c->lambda; A.mu = c->mu;
   A.tab = c->d_table; A.maps = c->d_gmaps; A.lay = *c->gather_lay; A.X0 = c->d_X0; A.x = c->d_x;
-  A.K = c->d_K; A.f = c->d_f; A.bad = c->d_flag + 1; A.stamps = nullptr;
+  A.K = c->d_K; A.f = c->d_f; A.bad = c->d_flag + 1; A.stamps = nullptr; A.ablate = 0;
   if (c->ngchunks <= 0) return FEAHIP_OK;
 #ifdef FEAHIP_DEBUG
   static unsigned long long *d_stamps = nullptr;
   static int stamps_cap = 0;
+  { const char *e = getenv("FEAHIP_GATHER_ABLATE"); A.ablate = e ? atoi(e) : 0; }
   const char *dbg = getenv("FEAHIP_GATHER_STAMPS");
   if (dbg && atoi(dbg)) {
     if (!d_stamps || stamps_cap < c->ngchunks) {
@@ -536,11 +600,10 @@ int launch_assemble_gather(feahip_ctx *c, bool doK, bool doF)
   if (run_len < 0) { const char *e = getenv("FEAHIP_GATHER_RUN"); run_len = e && atoi(e) > 0 ? atoi(e) : 8; }
   const int nruns = (c->ngchunks + run_len - 1) / run_len;
   const dim3 grid((nruns + 7) & ~7), blk(FEA_G_THREADS);
-  // LDS: coordinates (4 KB per 64 nodes) | element records, later the K tile (+1 double of alignment slack) and the residual partials
-  const int ncw = (A.lay.max_nodes + 63) >> 6;
+  // LDS: coordinates (48 bytes per node slot) | element records, later the K tile (+1 double of alignment slack) and the residual partials
   const int regK = std::max(A.lay.max_elems * GREC, ((A.lay.max_tile * 9 + 3) & ~1) + 3 * FEA_G_THREADS);
   const int regF = std::max(A.lay.max_elems * GREC_F, 3 * FEA_G_THREADS);
-  const int ldsK = ncw * 4096 + ((regK + 1) & ~1) * 8, ldsF = ncw * 4096 + ((regF + 1) & ~1) * 8;
+  const int ldsK = A.lay.max_nodes * 48 + ((regK + 1) & ~1) * 8, ldsF = A.lay.max_nodes * 48 + ((regF + 1) & ~1) * 8;
   const bool nh = c->model == FEAHIP_MODEL_COMPRESSIBLE_NEOHOOKEAN;
 #define G_LAUNCH(K, F, M, LDS)                                                                                         \
   do {                                                                                                               \

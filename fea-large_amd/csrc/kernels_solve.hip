@@ -301,8 +301,20 @@ static int spmv_grid(const feahip_ctx *c)
   return g < FEA_RED_BLOCKS ? (g > 0 ? g : 1) : FEA_RED_BLOCKS;
 }
 
+// k_spmv / k_spmv_jacobi give each lane blocks k and k+64 of a chunk's <= 128-block LDS tile; pattern.cpp puts a row
+// with more blocks than that into a chunk of its own, which these kernels cannot walk (assembly falls back to the
+// atomic path for such meshes, the multigrid refuses them): refuse instead of returning a wrong product.
+static int spmv_supported(feahip_ctx *c)
+{
+  if (c->max_rowlen <= FEA_CHUNK_BLOCKS) return FEAHIP_OK;
+  c->err = "the SpMV / PCG kernels need block rows of at most " + std::to_string(FEA_CHUNK_BLOCKS) +
+           " blocks (a node of this mesh has " + std::to_string(c->max_rowlen) + " neighbours)";
+  return FEAHIP_EINVAL;
+}
+
 int launch_spmv(feahip_ctx *c, const double *d_xv, double *d_yv)
 {
+  { const int rc = spmv_supported(c); if (rc) return rc; }
   hipLaunchKernelGGL(k_spmv, dim3(spmv_grid(c)), dim3(256), 0, c->stream, c->chunk0, c->nchunks_local, c->d_chunk,
                      c->d_rowptr, c->d_colidx, c->d_K, d_xv, d_yv, (const double *)nullptr,
                      (double *)nullptr, (const int *)nullptr);
@@ -690,6 +702,7 @@ int dist_solve_pcg(std::vector<feahip_ctx *> &R, int type, double tol, int max_i
 {
   Transport *T = R[0]->tr;
   feahip_ctx *c0 = R[0];
+  for (feahip_ctx *c : R) { const int rc = spmv_supported(c); if (rc) { c0->err = c->err; return rc; } }
   const int mode = (type == FEAHIP_CG) ? 0 : 1;
   if (type == FEAHIP_CHOLESKY) { tol = 1e-16; if (max_iter < 100000) max_iter = 100000; }
   int rc = enq_cg_start(R, T, mode, tol);
@@ -798,7 +811,9 @@ int time_pcg_iteration(feahip_ctx *c, int warmup, int iters, double *avg_ms)
 {
   std::vector<feahip_ctx *> R(1, c);
   Transport *T = c->tr;
-  int rc = enq_cg_start(R, T, 1, 0.0);
+  int rc = spmv_supported(c);
+  if (rc) return rc;
+  rc = enq_cg_start(R, T, 1, 0.0);
   if (rc) return rc;
   FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
   hipEvent_t e0, e1;

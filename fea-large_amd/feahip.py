@@ -51,6 +51,7 @@ ABI = {
     "feahip_get_solution": [C.c_void_p, _dp],
     "feahip_get_graddefs": [C.c_void_p, _dp],
     "feahip_get_stresses": [C.c_void_p, _dp],
+    "feahip_get_shape_gradients": [C.c_void_p, _dp, _dp],
     "feahip_matrix_nnz": [C.c_void_p, C.POINTER(C.c_longlong)],
     "feahip_get_matrix_yale": [C.c_void_p, _ip, _ip, _dp],
     "feahip_spmv": [C.c_void_p, _dp, _dp],
@@ -71,6 +72,7 @@ ABI = {
     "feahip_sync": [C.c_void_p],
     "feahip_time_kernel": [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp],
     "feahip_sizes": [C.c_void_p, C.POINTER(C.c_longlong)],
+    "feahip_assembly_in_use": [C.c_void_p, _ip],
 }
 
 _lib = None
@@ -369,6 +371,13 @@ class FeaSolver:
         self._chk(self._lib.feahip_get_nodes(self._ctx, _d(x)))
         return x
 
+    def shape_gradients(self):
+        """(grads[E][G][3][npe], detJ[E][G]) of the current configuration."""
+        g = np.zeros((self.E, self.G, 3, self.npe))
+        d = np.zeros((self.E, self.G))
+        self._chk(self._lib.feahip_get_shape_gradients(self._ctx, _d(g), _d(d)))
+        return g, d
+
     def forces(self):
         f = np.zeros(self.ndof)
         self._chk(self._lib.feahip_get_forces(self._ctx, _d(f)))
@@ -445,6 +454,12 @@ class FeaSolver:
         self._chk(self._lib.feahip_sizes(self._ctx, o))
         keys = ["N", "E", "npe", "G", "nnzb", "nchunks", "aux_bytes", "max_rowlen"]
         return dict(zip(keys, [int(v) for v in o]))
+
+    def assembly_in_use(self):
+        """The strategy the most recent assembly launch ran (what ASM_AUTO resolved to)."""
+        v = C.c_int(0)
+        self._chk(self._lib.feahip_assembly_in_use(self._ctx, C.byref(v)))
+        return v.value
 
 
 def comm_unique_id():

@@ -26,53 +26,35 @@ void fea_snapshots_free(fea_step_snapshot *steps, int n)
   for (i = 0; i < n; ++i) { free(steps[i].nodes); free(steps[i].stress0); steps[i].nodes = steps[i].stress0 = NULL; }
 }
 
-#define CALL(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+/* what solver_load_step_init keeps of a finished increment (fea_solver.c:605-636): the nodes and, for the
+ * export, the stress of Gauss point 0 of every element (:1480) */
+struct snap_sink { fea_step_snapshot *steps; int cap; double *S; };
+
+static int keep_snapshot(const fea_deck *d, feahip_ctx *ctx, int step, void *user)
+{
+  struct snap_sink *k = (struct snap_sink *)user;
+  const int G = d->gauss_nodes_count;
+  int e, rc;
+  if (!k->steps || step >= k->cap) return 0;
+  k->steps[step].nodes = (double *)malloc(sizeof(double) * 3 * (size_t)d->nodes_count);
+  k->steps[step].stress0 = (double *)malloc(sizeof(double) * 9 * (size_t)d->elements_count);
+  if (!k->S) k->S = (double *)malloc(sizeof(double) * 9 * (size_t)d->elements_count * G);
+  if (!k->steps[step].nodes || !k->steps[step].stress0 || !k->S) return FEAHIP_ENOMEM;
+  if ((rc = feahip_get_nodes(ctx, k->steps[step].nodes))) return rc;
+  if ((rc = feahip_get_stresses(ctx, k->S))) return rc;
+  for (e = 0; e < d->elements_count; ++e)
+    memcpy(k->steps[step].stress0 + (size_t)e * 9, k->S + (size_t)e * G * 9, sizeof(double) * 9);
+  return 0;
+}
 
 int fea_solve_with_snapshots(const fea_deck *d, feahip_ctx *ctx, void *logp, fea_step_snapshot *steps, int cap)
 {
-  FILE *log = (FILE *)logp;
-  int step, it, e;
-  double tolerance;
-  const int G = d->gauss_nodes_count;
-  double *S = NULL;
-  for (step = 0; step < d->load_increments_count; ++step) {                 /* fea_solver.c:163 */
-    it = 0;
-    CALL(feahip_update_nodes_with_bc(ctx, 1));
-    CALL(feahip_update_state(ctx, NULL));
-    CALL(feahip_create_stiffness(ctx));
-    CALL(feahip_stash_stiffness(ctx));
-    do {
-      it++;
-      CALL(feahip_create_residual_forces(ctx));
-      if (d->modified_newton) CALL(feahip_restore_stiffness(ctx));
-      else CALL(feahip_create_stiffness(ctx));
-      CALL(feahip_apply_prescribed_bc(ctx, 0));
-      CALL(feahip_solve_slae(ctx, d->solver_type, d->solver_tolerance, d->solver_max_iter, NULL, NULL));
-      CALL(feahip_energy(ctx, &tolerance));
-      if (log) {
-        fprintf(log, "Tolerance <X,R> = %e\n", tolerance);                   /* :212 */
-        fprintf(log, "Newton iteration %d finished\n", it);                  /* :213 */
-      }
-      CALL(feahip_update_nodes_with_solution(ctx, NULL));
-      CALL(feahip_update_state(ctx, NULL));
-    } while (fabs(tolerance) > d->desired_tolerance && it < d->max_newton_count);
-    if (log) fprintf(log, "Load increment %d finished\n", step + 1);         /* :224 */
-    if (it == d->max_newton_count) {                                         /* :225-231 */
-      if (log) fprintf(log, "Unable to finish load step in %d Newton iterations,exit\n", d->max_newton_count);
-      break;
-    }
-    if (steps && step < cap) {                                               /* :233-235 */
-      steps[step].nodes = (double *)malloc(sizeof(double) * 3 * (size_t)d->nodes_count);
-      steps[step].stress0 = (double *)malloc(sizeof(double) * 9 * (size_t)d->elements_count);
-      if (!S) S = (double *)malloc(sizeof(double) * 9 * (size_t)d->elements_count * G);
-      CALL(feahip_get_nodes(ctx, steps[step].nodes));
-      CALL(feahip_get_stresses(ctx, S));
-      for (e = 0; e < d->elements_count; ++e)
-        memcpy(steps[step].stress0 + (size_t)e * 9, S + (size_t)e * G * 9, sizeof(double) * 9);
-    }
-  }
-  free(S);
-  return step;
+  struct snap_sink k;
+  int done;
+  k.steps = steps; k.cap = cap; k.S = NULL;
+  done = fea_solve_steps(d, ctx, logp, keep_snapshot, &k);     /* the one Newton loop of the host side (fea_solve.c) */
+  free(k.S);
+  return done;
 }
 
 int fea_export_gmsh(const char *filename, const fea_deck *d, const fea_step_snapshot *steps, int nsteps)

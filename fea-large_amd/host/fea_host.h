@@ -74,6 +74,11 @@ int fea_deck_create_solver(const fea_deck *deck, int device, feahip_ctx **ctx,
  * to `log` when it is not NULL.  x_steps (may be NULL) receives the node
  * coordinates after every completed load step, [steps][N][3].
  * Returns the number of completed load steps, or a negative FEAHIP_E* code. */
+/* The load-increment / Newton loop itself (solve(), fea_solver.c:163-236): after every converged increment
+ * `after_step(deck, ctx, step, user)` runs where the reference takes its load_step snapshot (:233-235); a
+ * non-zero return aborts the loop with that code.  Returns the increments finished, or a negative FEAHIP_* code. */
+typedef int (*fea_step_fn)(const fea_deck *deck, feahip_ctx *ctx, int step, void *user);
+int fea_solve_steps(const fea_deck *deck, feahip_ctx *ctx, void *log /* FILE* */, fea_step_fn after_step, void *user);
 int fea_solve(const fea_deck *deck, feahip_ctx *ctx, void *log /* FILE* */,
               double *x_steps, int x_steps_cap);
 

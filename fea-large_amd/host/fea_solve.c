@@ -32,7 +32,10 @@ int fea_deck_create_solver(const fea_deck *d, int device, feahip_ctx **ctx, char
 
 #define CALL(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
 
-int fea_solve(const fea_deck *d, feahip_ctx *ctx, void *logp, double *x_steps, int x_steps_cap)
+/* solve() of fea_solver.c:163-236: THE load-increment / Newton loop of the host side (fea_solve and
+ * fea_solve_with_snapshots are this loop with two different things done after a converged increment, :233-235).
+ * Returns the number of finished increments, or a negative FEAHIP_* code. */
+int fea_solve_steps(const fea_deck *d, feahip_ctx *ctx, void *logp, fea_step_fn after_step, void *user)
 {
   FILE *log = (FILE *)logp;
   int step, it;
@@ -64,8 +67,23 @@ int fea_solve(const fea_deck *d, feahip_ctx *ctx, void *logp, double *x_steps, i
       if (log) fprintf(log, "Unable to finish load step in %d Newton iterations,exit\n", d->max_newton_count);
       break;
     }
-    if (x_steps && step < x_steps_cap)                                       /* :233-235 */
-      CALL(feahip_get_nodes(ctx, x_steps + (size_t)step * d->nodes_count * 3));
+    if (after_step) CALL(after_step(d, ctx, step, user));                    /* :233-235 */
   }
   return step;
+}
+
+struct node_sink { double *x; int cap; };
+
+static int keep_nodes(const fea_deck *d, feahip_ctx *ctx, int step, void *user)
+{
+  struct node_sink *k = (struct node_sink *)user;
+  if (!k->x || step >= k->cap) return 0;
+  return feahip_get_nodes(ctx, k->x + (size_t)step * d->nodes_count * 3);
+}
+
+int fea_solve(const fea_deck *d, feahip_ctx *ctx, void *logp, double *x_steps, int x_steps_cap)
+{
+  struct node_sink k;
+  k.x = x_steps; k.cap = x_steps_cap;
+  return fea_solve_steps(d, ctx, logp, keep_nodes, &k);
 }

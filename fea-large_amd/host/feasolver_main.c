@@ -20,7 +20,7 @@ int main(int argc, char **argv)
   feahip_ctx *ctx = NULL;
   char err[512], *msh;
   fea_step_snapshot *steps;
-  int done, rc;
+  int done, rc, cap, status = 0;
   if (argc < 2) {
     printf("Usage: fea_solve input_data.sexp\n");            /* fea_solver.c:328 */
     return 1;
@@ -37,22 +37,29 @@ int main(int argc, char **argv)
   }
   if (argc > 2 && strcmp(argv[2], "--multigrid") == 0 && feahip_set_preconditioner(ctx, 1))
     printf("multigrid preconditioner not used: %s\n", feahip_last_error(ctx));
-  steps = (fea_step_snapshot *)calloc((size_t)(deck.load_increments_count > 0 ? deck.load_increments_count : 1), sizeof *steps);
+  cap = deck.load_increments_count > 0 ? deck.load_increments_count : 1;
+  steps = (fea_step_snapshot *)calloc((size_t)cap, sizeof *steps);
   done = fea_solve_with_snapshots(&deck, ctx, stdout, steps, deck.load_increments_count);
   if (done < 0) {
+    /* a HIP failure or a broken-down linear solve: the reference's error() exits with EXIT_FAILURE
+     * (fea_solver.c:57-61); nothing is exported */
     fprintf(stderr, "feasolve error encountered: %s\n", feahip_last_error(ctx));
-    done = 0;
+    status = 1;
+  } else {
+    printf("Exporting data...\n");
+    msh = (char *)malloc(strlen(argv[1]) + 8);
+    fea_export_name(argv[1], msh);
+    /* a failed increment leaves current_load_step one lower (fea_solver.c:227), so the
+     * reference then drops the last completed step from the file: same here */
+    if (fea_export_gmsh(msh, &deck, steps, done == deck.load_increments_count ? done : done - 1)) {
+      fprintf(stderr, "could not write %s\n", msh);
+      status = 1;
+    }
+    free(msh);
   }
-  printf("Exporting data...\n");
-  msh = (char *)malloc(strlen(argv[1]) + 8);
-  fea_export_name(argv[1], msh);
-  /* a failed increment leaves current_load_step one lower (fea_solver.c:227), so the
-   * reference then drops the last completed step from the file: same here */
-  if (fea_export_gmsh(msh, &deck, steps, done == deck.load_increments_count ? done : done - 1))
-    fprintf(stderr, "could not write %s\n", msh);
-  fea_snapshots_free(steps, done);
-  free(steps); free(msh);
+  fea_snapshots_free(steps, cap);                      /* by capacity: an error may leave snapshots behind */
+  free(steps);
   feahip_destroy(ctx);
   fea_deck_free(&deck);
-  return 0;
+  return status;
 }

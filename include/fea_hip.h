@@ -203,6 +203,10 @@ int feahip_get_solution(feahip_ctx *ctx, double *u);          /* [3N]       */
  * (fea_solver.h:262-269), layout [E][G][3][3]                               */
 int feahip_get_graddefs(feahip_ctx *ctx, double *F);
 int feahip_get_stresses(feahip_ctx *ctx, double *S);
+/* shape_gradients[e][g] of the CURRENT configuration (fea_solver.h:200-205,
+ * filled by solver_create_current_shape_gradients, fea_solver.c:656-722,831):
+ * grads[((e*G + g)*3 + i)*npe + a] = dN_a/dx_i, detj[e*G + g] = det J.      */
+int feahip_get_shape_gradients(feahip_ctx *ctx, double *grads, double *detj);
 
 /* global_mtx in sp_matrix_yale shape (fea_solver.c:303-304): scalar CSR of
  * the full symmetric pattern, sorted columns.                               */
@@ -243,6 +247,9 @@ int feahip_time_kernel(feahip_ctx *ctx, int what, int warmup, int iters,
 /* sizes the roofline model needs: N, E, npe, G, block rows, blocks, and the
  * bytes of the auxiliary maps the kernels read                              */
 int feahip_sizes(feahip_ctx *ctx, long long *out8);
+/* the strategy (FEAHIP_ASM_*) the most recent assembly launch ran -- what
+ * FEAHIP_ASM_AUTO resolved to on this mesh; FEAHIP_ASM_AUTO before any launch */
+int feahip_assembly_in_use(feahip_ctx *ctx, int *strategy);
 
 #ifdef __cplusplus
 }

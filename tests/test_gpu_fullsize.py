@@ -123,7 +123,9 @@ def test_1m_lame_cylinder_a5_sharded_equals_unsharded():
     """configs[3] geometry and model at 1.2M linear tets (40 x 160 x 32 cells of
     the r-theta-z block): K symmetric and translation-free along the axis
     before BCs, reference state stress-free, and the rows one rank of 8 owns
-    come out bit-identical to the unsharded assembly."""
+    come out as in the unsharded assembly (to rounding: the gather chunks of a
+    shard start at its first row, so which blocks are written as transposes of
+    their mirror block differs; bit-identical with the staged visits)."""
     deck = mesh.cylinder_deck(40, 160, 32)
     assert len(deck.elements) == 40 * 160 * 32 * 6
     s = feahip.FeaSolver(deck)
@@ -141,7 +143,14 @@ def test_1m_lame_cylinder_a5_sharded_equals_unsharded():
     s.set_row_shard(5, 8)
     r0, r1 = s.owned_rows()
     s.create_stiffness_and_residual()
-    assert np.array_equal(s.spmv(a)[3 * r0:3 * r1], ya[3 * r0:3 * r1])
+    assert np.abs(s.spmv(a)[3 * r0:3 * r1] - ya[3 * r0:3 * r1]).max() < 1e-14 * np.abs(ya).max()
+    s.set_row_shard(0, 1)
+    s.set_assembly(feahip.ASM_STAGED)
+    s.create_stiffness_and_residual()
+    yb = s.spmv(a)
+    s.set_row_shard(5, 8)
+    s.create_stiffness_and_residual()
+    assert np.array_equal(s.spmv(a)[3 * r0:3 * r1], yb[3 * r0:3 * r1])
     s.close()
 
 
@@ -195,5 +204,12 @@ def test_10m_assembly_properties():
     s.set_row_shard(3, 8)
     r0, r1 = s.owned_rows()
     s.create_stiffness_and_residual()
-    assert np.array_equal(s.spmv(a)[3 * r0:3 * r1], ya[3 * r0:3 * r1])
+    assert np.abs(s.spmv(a)[3 * r0:3 * r1] - ya[3 * r0:3 * r1]).max() < 1e-14 * np.abs(ya).max()
+    s.set_row_shard(0, 1)
+    s.set_assembly(feahip.ASM_STAGED)
+    s.create_stiffness_and_residual()
+    yb = s.spmv(a)
+    s.set_row_shard(5, 8)
+    s.create_stiffness_and_residual()
+    assert np.array_equal(s.spmv(a)[3 * r0:3 * r1], yb[3 * r0:3 * r1])
     s.close()

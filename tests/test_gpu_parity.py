@@ -67,6 +67,8 @@ def test_tet4_assembly(model, dims):
     check_assembly(s, o)
     assert rel(s.graddefs(), o.graddefs()) < 1e-13
     assert rel(s.stresses(), o.stresses()) < 1e-12
+    g, d = s.shape_gradients()                          # a3: shape_gradients[e][g] (fea_solver.h:200-205)
+    assert rel(g, o.grads()) < 1e-13 and rel(d, o.detj()) < 1e-13
     s.close()
 
 
@@ -77,6 +79,8 @@ def test_tet10_reference_deck_assembly(decks_dir, name):
     check_assembly(s, o)
     assert rel(s.graddefs(), o.graddefs()) < 1e-12
     assert rel(s.stresses(), o.stresses()) < 1e-11
+    g, d = s.shape_gradients()
+    assert rel(g, o.grads()) < 1e-12 and rel(d, o.detj()) < 1e-12
     s.close()
 
 
@@ -431,12 +435,25 @@ def test_brick_fine_one_assembly(decks_dir, tmp_path):
     assert s.update_state() == 0                         # no inverted Gauss point with corrected ids
     off, idx, val = s.matrix_yale()
     assert len(val) == 8300196                           # scalar nnz of the deck
-    # spot-check 40 elements' worth of rows against the oracle's element matrices
+    # spot-check the block rows of 40 nodes against the sum of the oracle's element matrices of the elements around
+    # them (fea_solver.c:964-969: the rows an element adds to are 3 conn[e][a] + i)
     o = OracleSolver(deck)
     o.update_nodes_with_bc(1.0)
     o.update_state()
     import scipy.sparse as sp
     K = sp.csr_matrix((val, idx, off), shape=(s.ndof, s.ndof))
+    rng = np.random.default_rng(5)
+    picked = rng.choice(len(deck.nodes), 40, replace=False)
+    kscale = np.abs(val).max()
+    for a in picked:
+        es, las = np.nonzero(deck.elements == a)
+        want = np.zeros((3, s.ndof))
+        for e, la in zip(es, las):
+            kc, ks = o.element_stiffness(int(e))
+            cols = (3 * deck.elements[e][:, None] + np.arange(3)[None, :]).ravel()
+            np.add.at(want, (np.arange(3)[:, None], cols[None, :]), (kc + ks)[3 * la:3 * la + 3, :])
+        got = K[3 * a:3 * a + 3, :].toarray()
+        assert np.abs(got - want).max() < 1e-12 * kscale, int(a)
     sym = abs(K - K.T).max() / abs(K).max()
     assert sym < 1e-12
     t = np.zeros(s.ndof); t[1::3] = 1.0
@@ -488,7 +505,7 @@ def test_error_paths():
     with pytest.raises(feahip.FeaHipError, match="solver type"):
         s.solve_slae(9, 1e-10, 10)
     with pytest.raises(feahip.FeaHipError, match="strategy"):
-        s.set_assembly(8)
+        s.set_assembly(9)
     s.set_assembly(feahip.ASM_SHARED)                   # a 10-node strategy on linear tets: refused at the launch
     with pytest.raises(feahip.FeaHipError, match="10-node"):
         s.create_stiffness()
@@ -543,3 +560,36 @@ def test_feasolver_hip_command_line(decks_dir, tmp_path):
     res2 = subprocess.run([exe, str(deckfile), "--multigrid"], capture_output=True, text=True, timeout=300)
     assert res2.returncode == 0 and "multigrid preconditioner not used" in res2.stdout
     assert res2.stdout.count("Newton iteration") == 25
+
+
+def test_node_with_more_neighbours_than_the_spmv_tile():
+    """A fan of 140 tetrahedra pairs around one node: its block row has 143 blocks, more than the 128-block LDS
+    tile of the SpMV / PCG kernels (and of the row-owner assembly).  Assembly must still be right (AUTO falls back
+    to the atomic scatter), and the product / solve must refuse loudly instead of dropping blocks 128+."""
+    m = 140
+    ang = 2 * np.pi * np.arange(m) / m
+    ring = np.stack([np.cos(ang), np.sin(ang), np.zeros(m)], axis=1)
+    nodes = np.vstack([[0.0, 0.0, 0.0], ring, [0.0, 0.0, 0.7], [0.0, 0.0, -0.7]])
+    top, bot = m + 1, m + 2
+    el = []
+    for i in range(m):
+        a, b = 1 + i, 1 + (i + 1) % m
+        el.append([0, a, b, top])
+        el.append([0, b, a, bot])
+    deck = feahip.Deck(nodes=nodes, elements=np.array(el, dtype=np.int32), ele_type=feahip.TETRAHEDRA4, gauss_nodes_count=1,
+                       presc_node=[top, bot], presc_type=[7, 7], presc_values=np.zeros((2, 3)))
+    x = nodes * np.array([1.02, 0.99, 1.05]) + 1e-3 * np.sin(3 * nodes[:, [1, 2, 0]])
+    s, o = make_pair(deck, x)
+    o.update_state(); o.create_stiffness(); o.create_residual_forces()
+    s.create_stiffness_and_residual()
+    assert s.assembly_in_use() == feahip.ASM_ATOMIC
+    off, idx, val = s.matrix_yale()
+    assert np.array_equal(off, o.offsets()) and np.array_equal(idx, o.indexes())
+    assert off[3] - off[0] == 3 * 3 * (m + 3)                  # the centre's three rows: 143 blocks
+    assert rel(val, o.values()) < K_TOL and rel(s.forces(), o.forces()) < K_TOL
+    with pytest.raises(feahip.FeaHipError, match="block rows of at most 128"):
+        s.spmv(np.ones(s.ndof))
+    s.apply_prescribed_bc(0.0)
+    with pytest.raises(feahip.FeaHipError, match="block rows of at most 128"):
+        s.solve_slae(feahip.PCG_ILU, 1e-12, 100)
+    s.close(); o.close()

@@ -118,3 +118,50 @@ def test_lame_cylinder_small_strain_matches_lame_solution():
         assert sel.sum() >= 32
         assert np.abs(ur[sel] - expect).max() < 0.01 * d, (radius, ur[sel].min(), ur[sel].max(), expect)
     o.close()
+
+
+@pytest.mark.parametrize("name,closed", [("neohook_brick_analytical", nh_closed_form), ("a5_brick_analytical", a5_closed_form)])
+@pytest.mark.parametrize("n", [3, 60, 120])
+def test_oracle_at_finite_strain_homogeneous_state(decks_dir, name, closed, n):
+    """Pins the restated stress / residual / tangent loops at FINITE strain (k1 up to 2, the end of the decks' 120
+    increments) without a 120-step Newton run: put the reference's analytical deck into the exact homogeneous
+    uniaxial state x = A + diag(k2, k1, k2)(X - A) of the closed form and check
+      * sigma_yy at every Gauss point = the closed form, lateral stresses zero, F = diag(k2, k1, k2);
+      * the assembled residual vanishes at every node off the loaded faces (the state is an equilibrium);
+      * Neo-Hookean: the assembled tangent is the derivative of the assembled residual (central differences) --
+        ln J, the spatial tangent and both stiffness parts are exercised far from the reference configuration."""
+    deck = feahip.Deck.load(os.path.join(decks_dir, name + ".sexp"))
+    k1 = 1 + n * 0.05 / 6
+    k2, syy = closed(k1)
+    A = deck.nodes.min(axis=0)
+    x = A + (deck.nodes - A) * np.array([k2, k1, k2])
+    o = OracleSolver(deck)
+    o.set_nodes(x)
+    o.update_state()
+    S, F = o.stresses(), o.graddefs()
+    assert np.abs(S[:, :, 1, 1] - syy).max() < 1e-11 * abs(syy)
+    lateral = max(np.abs(S[:, :, 0, 0]).max(), np.abs(S[:, :, 2, 2]).max(), np.abs(S[:, :, 0, 1]).max())
+    assert lateral < 1e-10 * abs(syy)
+    assert np.abs(F - np.diag([k2, k1, k2])).max() < 1e-12
+    o.create_residual_forces()
+    f = o.forces().reshape(-1, 3)
+    y = deck.nodes[:, 1]
+    inner = (y > y.min() + 1e-9) & (y < y.max() - 1e-9)
+    area = k2 * k2                                   # deformed cross-section of the unit bar
+    assert np.abs(f[inner]).max() < 1e-10 * abs(syy) * area
+    assert np.abs(f[~inner][:, 1]).sum() == pytest.approx(2 * abs(syy) * area, rel=2e-6)     # the two faces carry sigma_yy * area (deck coordinates have 7 digits)
+    if "neohook" in name:
+        o.create_stiffness()
+        rng = np.random.default_rng(7)
+        d = rng.standard_normal(x.shape)
+        Kd = o.spmv(d.ravel())
+        eps = 1e-6
+        fs = []
+        for sgn in (+1, -1):
+            o.set_nodes(x + sgn * eps * d)
+            o.update_state()
+            o.create_residual_forces()
+            fs.append(o.forces().copy())
+        fd = (fs[1] - fs[0]) / (2 * eps)             # the residual vector holds MINUS the internal forces (fea_solver.c:1109)
+        assert np.abs(Kd - fd).max() < 2e-7 * np.abs(Kd).max()
+    o.close()
