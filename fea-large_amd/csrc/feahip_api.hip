@@ -64,7 +64,8 @@ int ensure_k(feahip_ctx *c)
   c->kb0 = c->h_rowptr[c->row0]; c->kb1 = c->h_rowptr[c->row1];
   const size_t n = (size_t)(c->kb1 - c->kb0) * 9 + 2;       // +2: the SpMV reads aligned 80-byte windows
   FEA_HIP_CHECK(c, hipMalloc((void **)&c->d_K_base, sizeof(double) * n));
-  FEA_HIP_CHECK(c, hipMemset(c->d_K_base, 0, sizeof(double) * n));
+  // on the context's own (non-blocking) stream: a null-stream memset is not ordered against the kernels that follow
+  FEA_HIP_CHECK(c, hipMemsetAsync(c->d_K_base, 0, sizeof(double) * n, c->stream));
   c->d_K = c->d_K_base - (size_t)c->kb0 * 9;
   return FEAHIP_OK;
 }
@@ -75,6 +76,29 @@ void release_k(feahip_ctx *c)
   if (c->d_Kstash_base) (void)hipFree(c->d_Kstash_base);
   c->d_K_base = c->d_Kstash_base = c->d_K = c->d_Kstash = nullptr;
   c->have_stash = false; c->k_bc = false; ++c->k_epoch;
+}
+
+// shared-state maps of 10-node elements for the assembly chunks this rank owns
+int ensure_quad(feahip_ctx *c)
+{
+  if (c->have_quad && c->quad_a0 == c->achunk0 && c->quad_n == c->nachunks_local) return FEAHIP_OK;
+  if (c->quad_failed || c->npe != 10 || !c->h_pat || c->h_conn.empty()) return FEAHIP_OK;
+  HostQuad hq;
+  build_host_quad(c->N, c->E, c->npe, c->h_conn.data(), *c->h_pat, c->achunk0, c->achunk0 + c->nachunks_local, hq);
+  for (void *p : {(void *)c->d_qdesc, (void *)c->d_qelem, (void *)c->d_qpair, (void *)c->d_qnode})
+    if (p) (void)hipFree(p);
+  c->d_qdesc = nullptr; c->d_qelem = c->d_qpair = nullptr; c->d_qnode = nullptr;
+  c->have_quad = false;
+  if (!hq.ok) { if (c->nranks == 1) c->quad_failed = true; return FEAHIP_OK; }
+  int rc;
+  if ((rc = dev_upload(c, &c->d_qdesc, hq.desc.data(), hq.desc.size()))) return rc;
+  if ((rc = dev_upload(c, &c->d_qelem, hq.qelem.data(), hq.qelem.size()))) return rc;
+  if ((rc = dev_upload(c, &c->d_qpair, hq.qpair.data(), hq.qpair.size()))) return rc;
+  if ((rc = dev_upload(c, &c->d_qnode, hq.qnode.data(), hq.qnode.size()))) return rc;
+  c->have_quad = true;
+  c->quad_a0 = c->achunk0; c->quad_n = c->nachunks_local;
+  c->quad_bytes = (long long)(hq.desc.size() * sizeof(QuadDesc) + hq.qelem.size() * 4 + hq.qpair.size() * 4 + hq.qnode.size() * 4);
+  return FEAHIP_OK;
 }
 
 int ensure_visits(feahip_ctx *c)
@@ -192,19 +216,8 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
     // the strategy allows (gather)
     c->h_conn.assign(elements, elements + (size_t)n_elems * npe);
   } else if ((rc = ensure_generic_maps(c))) return rc;
-  if (npe == 10) {
-    HostQuad hq;
-    build_host_quad(n_nodes, n_elems, npe, elements, hp, hq);
-    if (hq.ok) {
-      if ((rc = dev_upload(c, &c->d_qdesc, hq.desc.data(), hq.desc.size()))) return rc;
-      if ((rc = dev_upload(c, &c->d_qelem, hq.qelem.data(), hq.qelem.size()))) return rc;
-      if ((rc = dev_upload(c, &c->d_qpair, hq.qpair.data(), hq.qpair.size()))) return rc;
-      if ((rc = dev_upload(c, &c->d_qnode, hq.qnode.data(), hq.qnode.size()))) return rc;
-      c->have_quad = true;
-      c->quad_bytes = (long long)(hq.desc.size() * sizeof(QuadDesc) + hq.qelem.size() * 4 + hq.qpair.size() * 4 + hq.qnode.size() * 4);
-    }
-  }
-  if (!lin1) { delete c->h_pat; c->h_pat = nullptr; }          // nothing is built later for these meshes
+  if (npe == 10) c->h_conn.assign(elements, elements + (size_t)n_elems * npe);      // shared-state maps: built per shard on first use
+  if (!lin1 && npe != 10) { delete c->h_pat; c->h_pat = nullptr; }                   // nothing is built later for these meshes
   if ((rc = dev_zeros(c, &c->d_f, (size_t)c->ndof))) return rc;
   if ((rc = dev_zeros(c, &c->d_u, (size_t)c->ndof))) return rc;
   if ((rc = dev_zeros(c, &c->d_r, (size_t)c->ndof))) return rc;

@@ -91,7 +91,8 @@ struct feahip_ctx {
   uint32_t *d_vrec = nullptr;
   long long visit_bytes = 0;
   int nvisit_records = 0;      // length of vrec in records (whole passes per chunk)
-  bool have_quad = false;
+  bool have_quad = false, quad_failed = false;
+  int quad_a0 = -1, quad_n = 0;        // assembly chunks the quad maps were built for (this rank's)
   struct QuadDesc *d_qdesc = nullptr;
   uint32_t *d_qelem = nullptr, *d_qpair = nullptr;
   int *d_qnode = nullptr;
@@ -237,7 +238,8 @@ struct HostQuad {
   std::vector<uint32_t> qpair;       // el(6) | la(4)<<6 | lb(4)<<10 | tile position(8)<<14 | local row(4)<<22 | first pair of its visit<<26
   bool ok = false;
 };
-void build_host_quad(int N, int E, int npe, const int *conn, const HostPattern &hp, HostQuad &out);
+void build_host_quad(int N, int E, int npe, const int *conn, const HostPattern &hp, int p_lo, int p_hi, HostQuad &out);
+int ensure_quad(feahip_ctx *c);
 int launch_assemble_quad(feahip_ctx *c, bool doF);
 // GATHER assembly (kernels_gather.hip, gather.cpp): a 256-thread workgroup owns a run of consecutive block rows.
 // Per chunk the host prepares one fixed-stride record: header, the chunk's nodes (owned rows first), its distinct

@@ -426,3 +426,118 @@ void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int
   }
   out.ok = true;
 }
+
+// ---------------------------------------------------------------------------
+// Host-only digest of what the assembly maps of one rank say, row by row: for every block row a rank's maps cover,
+// a hash of the set of (row, column, element nodes, local row node, local column node) contributions they list
+// (mirror blocks expanded).  The maps of different shards are cut differently (the gather chunks of a rank start
+// at its first row), but what they SAY about a row must not depend on the cut: tests/test_host.py checks that the
+// digests of the ranks of a sharded run add up to the digest of the unsharded run.  No device is touched.
+// ---------------------------------------------------------------------------
+namespace {
+inline unsigned long long mix(unsigned long long h, unsigned long long v)
+{
+  h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+  return h * 0xBF58476D1CE4E5B9ull;
+}
+inline unsigned long long contribution_hash(int a, int b, const int g[4], int la, int lb)
+{
+  unsigned long long h = 0x1234567ull;
+  h = mix(h, (unsigned long long)a); h = mix(h, (unsigned long long)b);
+  for (int k = 0; k < 4; ++k) h = mix(h, (unsigned long long)g[k]);
+  h = mix(h, (unsigned long long)(la * 4 + lb));
+  return h;
+}
+}  // namespace
+
+void gather_row_digest(const HostGather &hg, const HostPattern &hp, unsigned long long *rowhash)
+{
+  const GatherLayout &lay = hg.lay;
+  for (int p = 0; p < hg.nchunks; ++p) {
+    const unsigned char *rec = hg.blob.data() + (size_t)p * lay.stride;
+    const GatherHeader &h = *reinterpret_cast<const GatherHeader *>(rec);
+    const int *nodes = reinterpret_cast<const int *>(rec + lay.o_nodes);
+    const uint32_t *elems = reinterpret_cast<const uint32_t *>(rec + lay.o_elems);
+    const uint32_t *tpos = reinterpret_cast<const uint32_t *>(rec + lay.o_bpos);
+    const uint16_t *clist = reinterpret_cast<const uint16_t *>(rec + lay.o_clist);
+    const uint16_t *dlist = reinterpret_cast<const uint16_t *>(rec + lay.o_dlist);
+    auto element_nodes = [&](int slot, int g[4]) {
+      for (int k = 0; k < 4; ++k) g[k] = nodes[(elems[slot] >> (8 * k)) & 255u];
+    };
+    auto row_of = [&](int pos) {                      // tile position -> global row
+      int a = h.r0;
+      while (a + 1 < h.r1 && hp.rowptr[a + 1] - h.b0 <= pos) ++a;
+      return a;
+    };
+    for (int t = 0; t < h.noffd; ++t) {
+      const int bpos = (int)(tpos[t] & 0xFFFFu), mpos = (int)(tpos[t] >> 16);
+      const int a = row_of(bpos), b = hp.colidx[h.b0 + bpos];
+      for (int k = 0; k < 2 * h.depth; ++k) {
+        const uint16_t w = clist[((size_t)(k / 2) * FEA_G_THREADS + t) * 2 + (k & 1)];
+        const int slot = w & 255, la = (w >> 8) & 3, lb = (w >> 10) & 3;
+        if (elems[slot] == 0xFFFFFFFFu) continue;     // empty list slot
+        int g[4];
+        element_nodes(slot, g);
+        rowhash[a] += contribution_hash(a, b, g, la, lb);
+        if (mpos != 0xFFFF) rowhash[b] += contribution_hash(b, a, g, lb, la);
+      }
+    }
+    for (int l = 0; l < 4 * (h.r1 - h.r0); ++l)
+      for (int k = 0; k < 2 * h.ddepth; ++k) {
+        const uint16_t w = dlist[((size_t)(k / 2) * 64 + l) * 2 + (k & 1)];
+        const int slot = w & 255, la = (w >> 8) & 3;
+        if (elems[slot] == 0xFFFFFFFFu) continue;
+        int g[4];
+        element_nodes(slot, g);
+        const int a = h.r0 + (l >> 2);
+        rowhash[a] += contribution_hash(a, a, g, la, la);
+      }
+  }
+}
+
+void quad_row_digest(const HostQuad &hq, const HostPattern &hp, unsigned long long *rowhash)
+{
+  for (const QuadDesc &d : hq.desc) {
+    for (int p = 0; p < d.npair; ++p) {
+      const uint32_t w = hq.qpair[(size_t)d.pair_off + p];
+      const int eli = (int)(w & 63u), la = (int)((w >> 6) & 15u), lb = (int)((w >> 10) & 15u), pos = (int)((w >> 14) & 255u);
+      const int a = d.r0 + (int)((w >> 22) & 15u), b = hp.colidx[d.b0 + pos];
+      const uint32_t *we = hq.qelem.data() + ((size_t)d.elem_off + eli) * 3;
+      unsigned long long h = 0x1234567ull;
+      h = mix(h, (unsigned long long)a); h = mix(h, (unsigned long long)b);
+      for (int k = 0; k < 10; ++k) h = mix(h, (unsigned long long)hq.qnode[(size_t)d.node_off + ((we[k / 4] >> (8 * (k % 4))) & 255u)]);
+      h = mix(h, (unsigned long long)(la * 16 + lb));
+      rowhash[a] += h;
+    }
+  }
+}
+
+extern "C" int feahip_host_assembly_digest(int n_nodes, int n_elems, int npe, const int *elements, int rank, int nranks,
+                                           unsigned long long *rowhash, int *rows)
+{
+  if (!elements || !rowhash || !rows || n_nodes <= 0 || n_elems <= 0 || nranks < 1 || rank < 0 || rank >= nranks) return FEAHIP_EINVAL;
+  HostPattern hp;
+  std::string err;
+  int rc = build_host_pattern(n_nodes, n_elems, npe, elements, hp, err);
+  if (rc) return rc;
+  int row0, row1;
+  shard_row_range(hp.chunk, rank, nranks, row0, row1);
+  rows[0] = row0; rows[1] = row1;
+  for (int a = 0; a < n_nodes; ++a) rowhash[a] = 0;
+  if (npe == 4) {
+    HostGather hg;
+    build_host_gather(n_nodes, n_elems, elements, hp, row0, row1, hg);
+    if (!hg.ok) return FEAHIP_EINVAL;
+    gather_row_digest(hg, hp, rowhash);
+  } else {
+    if (hp.super_achunk.empty()) return FEAHIP_EINVAL;
+    const int nchunks = (int)hp.chunk.size() - 1;
+    const int nsuper = (nchunks + FEA_SUPER_CHUNKS - 1) / FEA_SUPER_CHUNKS;
+    const int s0 = (int)((long long)nsuper * rank / nranks), s1 = (int)((long long)nsuper * (rank + 1) / nranks);
+    HostQuad hq;
+    build_host_quad(n_nodes, n_elems, npe, elements, hp, hp.super_achunk[s0], hp.super_achunk[s1], hq);
+    if (!hq.ok) return FEAHIP_EINVAL;
+    quad_row_digest(hq, hp, rowhash);
+  }
+  return FEAHIP_OK;
+}

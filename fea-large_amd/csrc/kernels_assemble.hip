@@ -319,9 +319,11 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
         if (c->have_visits) strat = FEAHIP_ASM_STAGED;
       }
     }
+    if (strat == FEAHIP_ASM_AUTO && c->npe == 10) { const int rc = ensure_quad(c); if (rc) return rc; }
     if (strat == FEAHIP_ASM_AUTO)
       strat = (c->have_quad && doK) ? FEAHIP_ASM_SHARED : (rowowner_ok ? FEAHIP_ASM_ROWOWNER : FEAHIP_ASM_ATOMIC);
   }
+  if (strat == FEAHIP_ASM_SHARED) { const int rc = ensure_quad(c); if (rc) return rc; }
   c->last_strategy = strat;
   if (strat == FEAHIP_ASM_SHARED && !doK && c->have_quad) strat = rowowner_ok ? FEAHIP_ASM_ROWOWNER : FEAHIP_ASM_ATOMIC;   // residual alone: visit kernel
   if (strat == FEAHIP_ASM_SHARED) {

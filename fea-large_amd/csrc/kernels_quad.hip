@@ -222,12 +222,12 @@ int launch_assemble_quad(feahip_ctx *c, bool doF)
 {
   if (c->npe != 10) { c->err = "shared-state assembly is built for 10-node elements"; return FEAHIP_EINVAL; }
   QuadArgs A;
-  A.chunk0 = c->achunk0; A.nchunks = c->nachunks_local; A.model = c->model; A.G = c->G;
+  A.chunk0 = 0; A.nchunks = c->quad_n; A.model = c->model; A.G = c->G;      // the maps hold this rank's chunks only
   A.lambda = c->lambda; A.mu = c->mu; A.tab = c->d_table; A.desc = c->d_qdesc; A.qelem = c->d_qelem; A.qpair = c->d_qpair;
   A.qnode = c->d_qnode; A.X0 = c->d_X0; A.x = c->d_x; A.rowptr = c->d_rowptr; A.diag = c->d_diag;
   A.K = c->d_K; A.f = c->d_f; A.bad = c->d_flag + 1;
-  if (c->nachunks_local <= 0) return FEAHIP_OK;
-  const dim3 grid((c->nachunks_local + 7) & ~7), blk(QUAD_NT);
+  if (c->quad_n <= 0) return FEAHIP_OK;
+  const dim3 grid((c->quad_n + 7) & ~7), blk(QUAD_NT);
   if (doF) hipLaunchKernelGGL((k_assemble_quad<10, true>), grid, blk, 0, c->stream, A);
   else     hipLaunchKernelGGL((k_assemble_quad<10, false>), grid, blk, 0, c->stream, A);
   FEA_HIP_CHECK(c, hipGetLastError());

@@ -600,19 +600,24 @@ void build_host_pairs(const int *conn, const HostPattern &hp, const HostVisits &
 // ---------------------------------------------------------------------------
 // maps of the shared-state assembly of 10-node elements (kernels_quad.hip)
 // ---------------------------------------------------------------------------
-void build_host_quad(int N, int E, int npe, const int *conn, const HostPattern &hp, HostQuad &out)
+// chunks [p_lo, p_hi) of the assembly partition only: a rank builds (and uploads) the maps of the rows it owns,
+// with offsets relative to its own arrays -- at 50M quadratic tets the pair list of the whole mesh (4.5e9 words)
+// neither fits 32-bit offsets nor belongs on every rank
+void build_host_quad(int N, int E, int npe, const int *conn, const HostPattern &hp, int p_lo, int p_hi, HostQuad &out)
 {
   (void)N; (void)E;
   out.ok = false;
   if (hp.achunk.size() < 2 || npe != 10 || hp.max_rowlen > 255) return;
-  const int np = (int)hp.achunk.size() - 1;
+  if (p_lo < 0 || p_hi > (int)hp.achunk.size() - 1 || p_lo > p_hi) return;
+  const int *achunk = hp.achunk.data() + p_lo;
+  const int np = p_hi - p_lo;
   out.desc.resize((size_t)np);
   // sizes first (prefix sums), then fill in parallel
   std::vector<int> nel((size_t)np, 0), nnd((size_t)np, 0);
   par_for(np, [&](int lo, int hi) {
     std::vector<int> el, nd;
     for (int p = lo; p < hi; ++p) {
-      const int r0 = hp.achunk[p], r1 = hp.achunk[p + 1];
+      const int r0 = achunk[p], r1 = achunk[p + 1];
       el.clear(); nd.clear();
       for (int q = hp.incptr[r0]; q < hp.incptr[r1]; ++q) el.push_back((int)(hp.inc_rows[q] & 0x0FFFFFFFu));
       std::sort(el.begin(), el.end());
@@ -625,7 +630,7 @@ void build_host_quad(int N, int E, int npe, const int *conn, const HostPattern &
   });
   size_t eo = 0, po = 0, no = 0;
   for (int p = 0; p < np; ++p) {
-    const int r0 = hp.achunk[p], r1 = hp.achunk[p + 1];
+    const int r0 = achunk[p], r1 = achunk[p + 1];
     QuadDesc &d = out.desc[p];
     d.r0 = r0; d.r1 = r1; d.b0 = hp.rowptr[r0]; d.nb = hp.rowptr[r1] - d.b0;
     d.elem_off = (int)eo; d.nelem = nel[p];

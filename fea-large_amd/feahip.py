@@ -72,6 +72,7 @@ ABI = {
     "feahip_sync": [C.c_void_p],
     "feahip_time_kernel": [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp],
     "feahip_sizes": [C.c_void_p, C.POINTER(C.c_longlong)],
+    "feahip_host_assembly_digest": [C.c_int, C.c_int, C.c_int, _ip, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), _ip],
     "feahip_assembly_in_use": [C.c_void_p, _ip],
 }
 
@@ -460,6 +461,18 @@ class FeaSolver:
         v = C.c_int(0)
         self._chk(self._lib.feahip_assembly_in_use(self._ctx, C.byref(v)))
         return v.value
+
+
+def host_assembly_digest(elements, n_nodes, rank=0, nranks=1):
+    """(rowhash[N] uint64, (row0, row1)) of the assembly maps `rank` of `nranks` builds on the host (no device)."""
+    el = np.ascontiguousarray(elements, dtype=np.int32)
+    h = np.zeros(n_nodes, dtype=np.uint64)
+    rows = np.zeros(2, dtype=np.int32)
+    rc = load_library().feahip_host_assembly_digest(n_nodes, el.shape[0], el.shape[1], _i(el), rank, nranks,
+                                                    h.ctypes.data_as(C.POINTER(C.c_ulonglong)), _i(rows))
+    if rc:
+        raise FeaHipError(f"feahip_host_assembly_digest failed ({rc})")
+    return h, (int(rows[0]), int(rows[1]))
 
 
 def comm_unique_id():

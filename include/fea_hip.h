@@ -191,6 +191,15 @@ int feahip_group_solve(feahip_ctx **ctxs, int n, int load_increments, int max_ne
 int feahip_shard_plan(int n_nodes, int n_elems, int npe, const int *elements, int rank,
                       int nranks, int *counts, int *peers, int *send_off, int *recv_off,
                       int *send_idx, int *recv_idx);
+/* Host-only (no device is touched): what the assembly maps `rank` of `nranks`
+ * builds for ITS block rows say, as one hash per row of the set of (row,
+ * column, element, local row node, local column node) contributions they
+ * list; rows[0..1] = the rows the rank owns, rowhash[a] = 0 for every other
+ * row.  The maps of a shard are cut differently from the unsharded ones, what
+ * they say about a row must not be: the hashes of all ranks add up to the
+ * unsharded ones (tests/test_host.py).                                      */
+int feahip_host_assembly_digest(int n_nodes, int n_elems, int npe, const int *elements, int rank, int nranks,
+                                unsigned long long *rowhash, int *rows);
 
 /* ---- reference-shaped views -------------------------------------------- */
 

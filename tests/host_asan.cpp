@@ -1,4 +1,4 @@
-// host-only sanitizer run over the map builders (pattern, visits, pairs, patches, quad, multigrid setup)
+// host-only sanitizer run over the map builders (pattern, visits, pairs, patches, gather, quad, multigrid setup)
 #include "feahip_internal.h"
 #include "amg.h"
 #include <cstdio>
@@ -28,10 +28,16 @@ int main()
       HostPatches pt; build_host_patches(N, E, conn.data(), hp, pt);
       HostVisits hv; build_host_visits(N, E, conn.data(), hp, hv);
       HostPairs pr; build_host_pairs(conn.data(), hp, hv, pr);
-      printf("tet4: N=%d E=%d chunks=%zu achunks=%zu patches=%d visits=%d pairs=%d\n", N, E, hp.chunk.size() - 1, hp.achunk.size() - 1, (int)pt.ok, (int)hv.ok, (int)pr.ok);
+      HostGather hg; build_host_gather(N, E, conn.data(), hp, 0, N, hg);
+      HostGather hs; build_host_gather(N, E, conn.data(), hp, N / 3, 2 * N / 3, hs);      // a rank's rows only
+      printf("tet4: N=%d E=%d chunks=%zu achunks=%zu patches=%d visits=%d pairs=%d gather=%d/%d gather chunks=%d evaluations per element=%.2f\n", N, E,
+             hp.chunk.size() - 1, hp.achunk.size() - 1, (int)pt.ok, (int)hv.ok, (int)pr.ok, (int)hg.ok, (int)hs.ok, hg.nchunks,
+             hg.distinct_elems ? (double)hg.total_evals / (double)hg.distinct_elems : 0.0);
     } else {
-      HostQuad hq; build_host_quad(N, E, npe, conn.data(), hp, hq);
-      printf("tet10: N=%d E=%d chunks=%zu achunks=%zu quad=%d pairs=%zu\n", N, E, hp.chunk.size() - 1, hp.achunk.size() - 1, (int)hq.ok, hq.qpair.size());
+      const int na = (int)hp.achunk.size() - 1;
+      HostQuad hq; build_host_quad(N, E, npe, conn.data(), hp, 0, na, hq);
+      HostQuad hs; build_host_quad(N, E, npe, conn.data(), hp, na / 3, 2 * na / 3, hs);      // a rank's chunks only
+      printf("tet10: N=%d E=%d chunks=%zu achunks=%zu quad=%d/%d pairs=%zu\n", N, E, hp.chunk.size() - 1, hp.achunk.size() - 1, (int)hq.ok, (int)hs.ok, hq.qpair.size());
     }
     std::vector<HostAmgLevel> lv;
     const bool ok = build_host_amg(hp.rowptr, hp.colidx, pos, 0, N, lv);

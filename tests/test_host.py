@@ -230,9 +230,54 @@ def test_host_map_builders_under_sanitizers(tmp_path):
     cmd = ["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17",
            "-I" + src, "-I" + os.path.join(root, "include"), "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-o", exe,
            os.path.join(root, "tests", "host_asan.cpp")] + [os.path.join(src, f) for f in
-                                                            ("pattern.cpp", "patches.cpp", "amg_setup.cpp")] + ["-lpthread"]
+                                                            ("pattern.cpp", "patches.cpp", "gather.cpp", "shard.cpp", "amg_setup.cpp")] + ["-lpthread"]
     subprocess.run(cmd, check=True, capture_output=True, timeout=600)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "ERROR" not in r.stderr and "runtime error" not in r.stderr
-    assert "patches=1 visits=1 pairs=1" in r.stdout and "quad=1" in r.stdout and r.stdout.count("amg: ok=1") == 2
+    assert "patches=1 visits=1 pairs=1 gather=1/1" in r.stdout and "quad=1/1" in r.stdout and r.stdout.count("amg: ok=1") == 2
+
+
+@pytest.mark.parametrize("quadratic,brick", [(False, None), (False, (4, 2, 2)), (True, None)])
+def test_per_rank_assembly_maps_say_what_the_unsharded_maps_say(quadratic, brick):
+    """A rank of a sharded run builds the assembly maps of ITS block rows only (gather chunks for linear tets,
+    shared-state chunks for 10-node tets), cut from its first row -- so they are not slices of the unsharded maps,
+    but what they say about a row must be the same: for every row, the set of (row, column, element, local row
+    node, local column node) contributions listed (mirror blocks expanded), compared through one hash per row.
+    Also an independent restatement: the hash of a row from the element list alone.  Host only, no device."""
+    import mesh
+    nodes, el = mesh.kuhn_block(4, 30, 3, quadratic=quadratic, brick=brick)
+    N = len(nodes)
+    whole, (a, b) = feahip.host_assembly_digest(el, N)
+    assert (a, b) == (0, N) and np.all(whole != 0)
+    for nranks in (2, 3):
+        total = np.zeros(N, dtype=np.uint64)
+        edge = 0
+        for r in range(nranks):
+            h, (r0, r1) = feahip.host_assembly_digest(el, N, r, nranks)
+            assert r0 == edge and r1 > r0
+            edge = r1
+            assert np.all(h[:r0] == 0) and np.all(h[r1:] == 0)          # nothing about rows of other ranks
+            total += h
+        assert edge == N
+        assert np.array_equal(total, whole)
+    # independent restatement of the digest from the element list (linear tets): every (a, b != a) pair of every
+    # element contributes once to row a, every (a, a) once
+    if not quadratic:
+        M = (1 << 64) - 1
+
+        def mix(h, v):
+            h ^= (v + 0x9E3779B97F4A7C15 + ((h << 6) & M) + (h >> 2)) & M
+            return (h * 0xBF58476D1CE4E5B9) & M
+        want = [0] * N
+        for e in el[:200]:
+            g = [int(v) for v in e]
+            for la in range(4):
+                for lb in range(4):
+                    h = 0x1234567
+                    for v in (g[la], g[lb], *g, la * 4 + lb):
+                        h = mix(h, v)
+                    want[g[la]] = (want[g[la]] + h) & M
+        touched = set(int(v) for v in el[:200].ravel())
+        only = [n for n in touched if not np.any((el[200:] == n))]          # rows whose elements are all among the first 200
+        assert only and all(int(whole[n]) == want[n] for n in only)
