@@ -333,6 +333,7 @@ void k_assemble_gather(GatherArgs A, int run_len)
   const int t = threadIdx.x;
 #ifdef FEAHIP_DEBUG
   unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), real0 = __builtin_amdgcn_s_memrealtime();
 #endif
   // XCD-aware order: workgroups b and b+8 share an L2; each XCD gets a contiguous eighth of the runs so that
   // neighbouring chunks re-read each other's halo coordinates from the same L2 (speed only)
@@ -347,6 +348,9 @@ void k_assemble_gather(GatherArgs A, int run_len)
   const unsigned char *rec = A.maps + (size_t)(A.chunk0 + chunk) * stride;
   const bool node_lane = t < A.lay.max_nodes;
 
+  // the Gauss weight is read ONCE: a load inside the loop would be the youngest memory operation when the state
+  // phase needs it, and waiting for it waits for every prefetch issued before it (in-order counter)
+  const double gauss_w = A.tab->w[0];
   // ---- prologue: maps and coordinates of the first chunk, nothing to hide behind
   GMaps mn;                                                   // "next": the chunk about to be worked on
   g_load_maps<DOK, DOF>(A.lay, rec, t, mn);
@@ -362,13 +366,17 @@ void k_assemble_gather(GatherArgs A, int run_len)
     const int cn = min(chunk + 1, cend - 1);
     node1 = reinterpret_cast<const int *>(A.maps + (size_t)(A.chunk0 + cn) * stride + A.lay.o_nodes)[t & (FEA_G_MAX_NODES - 1)];
   }
+  // nothing is pending when the loop is entered: otherwise the loop header inherits "node1 may still be in
+  // flight" and the compiler waits for everything (s_waitcnt vmcnt(0)) at the top of EVERY iteration
+  asm volatile("" : : "v"(mn.eids), "v"(mn.tpos), "v"(mn.cw[0]), "v"(mn.cw[1]), "v"(mn.cw[2]), "v"(mn.cw[3]),
+               "v"(mn.vw[0]), "v"(mn.vw[1]), "v"(mn.kd), "v"(mn.vb), "v"(mn.ve), "v"(node1), "v"(gauss_w));
   G_BARRIER();
 
   for (;;) {
     G_STAMP(0);
     const bool more = chunk + 1 < cend;
     const GatherHeader h = hn;
-    g_v8i h8; g_v4i h4;
+    int hword;
     const GMaps m = mn;
     const int nrows = h.r1 - h.r0;
     rec = A.maps + (size_t)(A.chunk0 + chunk) * stride;
@@ -380,11 +388,13 @@ void k_assemble_gather(GatherArgs A, int run_len)
     {
       const int c1 = min(chunk + 1, cend - 1), c2 = min(chunk + 2, cend - 1);
       const unsigned char *rec1 = A.maps + (size_t)(A.chunk0 + c1) * stride;
-      asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20" : "=s"(h8), "=s"(h4) : "s"(rec1) : "memory");
+      // the header of the next chunk as a VECTOR load (lane l holds word l, read back with v_readlane): a scalar
+      // load shares its counter with the LDS, and every barrier's wait for the LDS would wait for it as well
+      hword = reinterpret_cast<const int *>(rec1)[t & 15];
       g_load_maps<DOK, DOF>(A.lay, rec1, t, mn);
       const size_t n1 = (size_t)(node_lane ? node1 : 0);
-      ca0 = *reinterpret_cast<const double2 *>(A.x + n1 * 4); ca1 = *reinterpret_cast<const double2 *>(A.x + n1 * 4 + 2);
-      cc0 = *reinterpret_cast<const double2 *>(A.X0 + n1 * 4); cc1 = *reinterpret_cast<const double2 *>(A.X0 + n1 * 4 + 2);
+      ca0 = *reinterpret_cast<const double2 *>(A.x + n1 * 4); ca1.x = A.x[n1 * 4 + 2];
+      cc0 = *reinterpret_cast<const double2 *>(A.X0 + n1 * 4); cc1.x = A.X0[n1 * 4 + 2];
       node1 = reinterpret_cast<const int *>(A.maps + (size_t)(A.chunk0 + c2) * stride + A.lay.o_nodes)[t & (FEA_G_MAX_NODES - 1)];
     }
 
@@ -403,7 +413,7 @@ void k_assemble_gather(GatherArgs A, int run_len)
       double R[REC];
       double detJ;
       if (G_ABL(8)) { detJ = 1.0; for (int q = 0; q < REC; ++q) R[q] = xe[q & 3][q % 3] + Xe[(q >> 2) & 3][q % 3]; }
-      else detJ = NH ? lintet_record_nh<DOK>(xe, Xe, A.tab->w[0], A.lambda, A.mu, R)
+      else detJ = NH ? lintet_record_nh<DOK>(xe, Xe, gauss_w, A.lambda, A.mu, R)
                      : lintet_record_any<DOK>(xe, Xe, A.tab, A.model, A.lambda, A.mu, R);
       if (!(detJ > 0.0)) {                             // rare, kept off the fast path
         if (DOK) {                                     // counted by the chunk that owns its lowest-numbered node
@@ -490,16 +500,23 @@ void k_assemble_gather(GatherArgs A, int run_len)
       if ((t & 3) == 0 && t - G_TASK_THREADS < 4 * nrows) {
         double *o = sK + m.kd * 9;
         o[0] = dg[0]; o[1] = dg[1]; o[2] = dg[2]; o[3] = dg[1]; o[4] = dg[3]; o[5] = dg[4]; o[6] = dg[2]; o[7] = dg[4]; o[8] = dg[5];
-        if (DOF) {
-          double *fo = A.f + (size_t)(h.r0 + ((t - G_TASK_THREADS) >> 2)) * 3;
-          fo[0] = fa[0]; fo[1] = fa[1]; fo[2] = fa[2];
-        }
       }
     }
     if (!DOK && t < h.nvthr) { sF[t * 3] = fa[0]; sF[t * 3 + 1] = fa[1]; sF[t * 3 + 2] = fa[2]; }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(h8), "+s"(h4) : : "memory");     // and so has its header
-    hn.r0 = h8[0]; hn.r1 = h8[1]; hn.b0 = h8[2]; hn.nb = h8[3]; hn.nnode = h8[4]; hn.nelem = h8[5]; hn.noffd = h8[6]; hn.depth = h8[7];
-    hn.nvthr = h4[0]; hn.vdepth = h4[1]; hn.ddepth = h4[2];
+    // The prefetched words of the next chunk are "used" HERE, before this chunk's row stores are issued: the
+    // hardware counts loads and stores in one in-order counter and the number of stores is not a compile-time
+    // constant, so a first use after the stores would make the compiler wait for everything in flight, the
+    // stores just issued included (s_waitcnt vmcnt(0): measured, a third of the chunk time).  Here only the
+    // prefetches themselves are younger, they were requested a state + gather phase ago, and nothing ever waits
+    // for a store.
+    asm volatile("" : : "v"(mn.eids), "v"(mn.tpos), "v"(mn.cw[0]), "v"(mn.cw[1]), "v"(mn.cw[2]), "v"(mn.cw[3]),
+                 "v"(mn.vw[0]), "v"(mn.vw[1]), "v"(mn.kd), "v"(mn.vb), "v"(mn.ve), "v"(node1), "v"(hword));
+    hn.r0 = __builtin_amdgcn_readlane(hword, 0); hn.r1 = __builtin_amdgcn_readlane(hword, 1);
+    hn.b0 = __builtin_amdgcn_readlane(hword, 2); hn.nb = __builtin_amdgcn_readlane(hword, 3);
+    hn.nnode = __builtin_amdgcn_readlane(hword, 4); hn.nelem = __builtin_amdgcn_readlane(hword, 5);
+    hn.noffd = __builtin_amdgcn_readlane(hword, 6); hn.depth = __builtin_amdgcn_readlane(hword, 7);
+    hn.nvthr = __builtin_amdgcn_readlane(hword, 8); hn.vdepth = __builtin_amdgcn_readlane(hword, 9);
+    hn.ddepth = __builtin_amdgcn_readlane(hword, 10);
     G_BARRIER();
     G_STAMP(4);
     if (!DOK) {                                        // f_a = sum of the row's partials
@@ -512,6 +529,11 @@ void k_assemble_gather(GatherArgs A, int run_len)
       }
     }
     G_STAMP(5);
+    if (DOK && DOF && t >= G_TASK_THREADS && (t & 3) == 0 && t - G_TASK_THREADS < 4 * nrows) {
+      // the row's residual, stored with the rows (after the wait for the prefetches above: no store before it)
+      double *fo = A.f + (size_t)(h.r0 + ((t - G_TASK_THREADS) >> 2)) * 3;
+      fo[0] = fa[0]; fo[1] = fa[1]; fo[2] = fa[2];
+    }
     if (DOK) {
       // ---- phase 3: stream the finished rows out, 16-byte LDS reads and HBM stores
       double *Kd = A.K + (size_t)h.b0 * 9;
@@ -537,6 +559,8 @@ void k_assemble_gather(GatherArgs A, int run_len)
   if (A.stamps && (t & 63) == 0) {                     // one line per wave: [run][wave][8]
     unsigned long long *o = A.stamps + ((size_t)ridx * 4 + (t >> 6)) * 8;
     for (int i = 0; i < 6; ++i) o[i] = sa[i];
+    o[6] = __builtin_amdgcn_s_memtime() - clk0;          // shader cycles of this run ...
+    o[7] = __builtin_amdgcn_s_memrealtime() - real0;     // ... and 100 MHz ticks: their ratio is the in-kernel clock
   }
 #endif
 }
@@ -597,7 +621,7 @@ int launch_assemble_gather(feahip_ctx *c, bool doK, bool doF)
   }
 #endif
   static int run_len = -1;           // chunks per workgroup run (FEAHIP_GATHER_RUN: tuning only, results unchanged)
-  if (run_len < 0) { const char *e = getenv("FEAHIP_GATHER_RUN"); run_len = e && atoi(e) > 0 ? atoi(e) : 8; }
+  if (run_len < 0) { const char *e = getenv("FEAHIP_GATHER_RUN"); run_len = e && atoi(e) > 0 ? atoi(e) : 16; }
   const int nruns = (c->ngchunks + run_len - 1) / run_len;
   const dim3 grid((nruns + 7) & ~7), blk(FEA_G_THREADS);
   // LDS: coordinates (48 bytes per node slot) | element records, later the K tile (+1 double of alignment slack) and the residual partials
@@ -627,6 +651,8 @@ int launch_assemble_gather(feahip_ctx *c, bool doK, bool doF)
       for (int i = 0; i < nruns; ++i)
         for (int w = 0; w < 4; ++w)
           for (int q = 0; q < 8; ++q) sum[w][q] += (double)hst[((size_t)i * 4 + w) * 8 + q];
+      fprintf(stderr, "[gather stamps] in-kernel clock %.0f MHz (s_memtime / s_memrealtime x 100 MHz over a run), run = %.0f shader cycles for %d chunks\n",
+              sum[0][7] > 0 ? 100.0 * sum[0][6] / sum[0][7] : 0.0, sum[0][6] / nruns, run_len);
       for (int w = 0; w < 4; ++w)
         fprintf(stderr, "[gather stamps K=%d F=%d wave %d, per chunk] state %.0f  prefetch+gather %.0f  barrier %.0f  tile %.0f  diag+drain %.0f  writeout %.0f cycles\n",
                 (int)doK, (int)doF, w, sum[w][0] / c->ngchunks, sum[w][1] / c->ngchunks, sum[w][2] / c->ngchunks, sum[w][3] / c->ngchunks,
