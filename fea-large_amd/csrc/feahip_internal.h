@@ -225,6 +225,7 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
 #define FEA_QUAD_PAIRS 256            // pairs of a multi-row chunk (a single row may have more)
 #define FEA_QUAD_ELEMS 64             // distinct elements of a chunk (6-bit index in a pair record)
 #define FEA_QUAD_NODES 126            // coordinate tile: distinct nodes of the chunk's elements
+#define FEA_QUAD_VISITS 96            // (row, element) visits of a chunk: one row-vector record per visit and Gauss point of a batch
 struct QuadDesc {                    // 40 bytes, one per chunk
   int r0, r1, b0, nb;
   int elem_off, nelem;               // into qelem (3 words per element)

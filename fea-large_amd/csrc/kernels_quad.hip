@@ -90,16 +90,28 @@ void k_assemble_quad(QuadArgs A)
     for (int t = lane; t < nrows * 3; t += QUAD_NT) sF[t] = 0.0;
 
   const int ne = d.nelem;
+  // The first QUAD_NT pair words of the chunk live in registers across the batches, and a rule of at most
+  // FEA_QUAD_BATCH_GAUSS points has its whole table in LDS from the start: no batch begins by waiting for global
+  // memory (each such wait cost a full memory latency per batch with four workgroups per CU to hide it).
+  const uint32_t w_first = lane < d.npair ? A.qpair[(size_t)d.pair_off + lane] : 0u;
+  const bool whole_table = A.G <= FEA_QUAD_BATCH_GAUSS;
+  if (whole_table) {
+    for (int t = lane; t < A.G; t += QUAD_NT) sTw[t] = A.tab->w[t];
+    for (int t = lane; t < A.G * 3 * NPE; t += QUAD_NT) (&sTd[0][0][0])[t] = A.tab->dN[t / (3 * NPE)][(t / NPE) % 3][t % NPE];
+  }
   int gb = QUAD_ENTRIES / ne;
   gb = gb < 1 ? 1 : (gb > A.G ? A.G : gb);
   gb = gb > FEA_QUAD_BATCH_GAUSS ? FEA_QUAD_BATCH_GAUSS : gb;
   gb = (A.G + (A.G + gb - 1) / gb - 1) / ((A.G + gb - 1) / gb);          // same number of batches, evenly filled
   for (int g0 = 0; g0 < A.G; g0 += gb) {
     const int ng = (A.G - g0 < gb) ? (A.G - g0) : gb;
-    __syncthreads();                                   // the previous batch has been read
-    for (int t = lane; t < ng; t += QUAD_NT) sTw[t] = A.tab->w[g0 + t];
-    for (int t = lane; t < ng * 3 * NPE; t += QUAD_NT) (&sTd[0][0][0])[t] = A.tab->dN[g0 + t / (3 * NPE)][(t / NPE) % 3][t % NPE];
-    __syncthreads();
+    const int tb = whole_table ? g0 : 0;               // first row of the batch in the LDS table
+    __syncthreads();                                   // the previous batch has been read (first batch: the tiles are staged)
+    if (!whole_table) {
+      for (int t = lane; t < ng; t += QUAD_NT) sTw[t] = A.tab->w[g0 + t];
+      for (int t = lane; t < ng * 3 * NPE; t += QUAD_NT) (&sTd[0][0][0])[t] = A.tab->dN[g0 + t / (3 * NPE)][(t / NPE) % 3][t % NPE];
+      __syncthreads();
+    }
     // ---- phase 1: state of (element, Gauss point) entries
     if (lane < ne * ng) {
       const int el = lane / ng, tg = lane % ng;
@@ -115,7 +127,7 @@ void k_assemble_quad(QuadArgs A)
         const double Xc[3] = {sX[nd[k] * 3], sX[nd[k] * 3 + 1], sX[nd[k] * 3 + 2]};
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          const double dn = sTd[tg][i][k];
+          const double dn = sTd[tb + tg][i][k];
 #pragma unroll
           for (int j = 0; j < 3; ++j) { J[i][j] += dn * xc[j]; M[i][j] += dn * Xc[j]; }
         }
@@ -142,12 +154,12 @@ void k_assemble_quad(QuadArgs A)
       sS[QS_SIG + 4][lane] = dead ? 0.0 : sig[1][2]; sS[QS_SIG + 5][lane] = dead ? 0.0 : sig[2][2];
       sS[QS_L1][lane] = dead ? 0.0 : l1;
       sS[QS_M1][lane] = dead ? 0.0 : m1;
-      sS[QS_VOL][lane] = dead ? 0.0 : sTw[tg] * fabs(detJ);
+      sS[QS_VOL][lane] = dead ? 0.0 : sTw[tb + tg] * fabs(detJ);
     }
     __syncthreads();
     // ---- phase 2: blocks of (row node, element, column node) pairs over the batch, then into the K tile
     for (int p0 = lane; p0 < d.npair; p0 += QUAD_NT) {
-      const uint32_t w = A.qpair[(size_t)d.pair_off + p0];
+      const uint32_t w = p0 < QUAD_NT ? w_first : A.qpair[(size_t)d.pair_off + p0];
       const int el = w & 63u, la = (w >> 6) & 15u, lb = (w >> 10) & 15u;
       double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, fa[3] = {0, 0, 0};
       for (int t = 0; t < ng; ++t) {
@@ -157,8 +169,8 @@ void k_assemble_quad(QuadArgs A)
         for (int i = 0; i < 3; ++i)
 #pragma unroll
           for (int m = 0; m < 3; ++m) Ji[i][m] = sS[QS_JI + 3 * i + m][ent];
-        const double da[3] = {sTd[t][0][la], sTd[t][1][la], sTd[t][2][la]};
-        const double db[3] = {sTd[t][0][lb], sTd[t][1][lb], sTd[t][2][lb]};
+        const double da[3] = {sTd[tb + t][0][la], sTd[tb + t][1][la], sTd[tb + t][2][la]};
+        const double db[3] = {sTd[tb + t][0][lb], sTd[tb + t][1][lb], sTd[tb + t][2][lb]};
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           ga[i] = Ji[i][0] * da[0] + Ji[i][1] * da[1] + Ji[i][2] * da[2];

@@ -638,7 +638,7 @@ void build_host_quad(int N, int E, int npe, const int *conn, const HostPattern &
     d.node_off = (int)no; d.nnode = nnd[p];
     eo += (size_t)d.nelem; po += (size_t)d.npair; no += (size_t)d.nnode;
     if (d.nelem > FEA_QUAD_ELEMS || d.nb > FEA_QUAD_BLOCKS || d.nnode > FEA_QUAD_NODES || r1 - r0 > FEA_CHUNK_ROWS ||
-        po > 0x7FFFFFFFull) { out.desc.clear(); return; }
+        hp.incptr[r1] - hp.incptr[r0] > FEA_QUAD_VISITS || po > 0x7FFFFFFFull) { out.desc.clear(); return; }
   }
   out.qelem.assign(eo * 3, 0u); out.qpair.resize(po); out.qnode.resize(no);
   par_for(np, [&](int lo, int hi) {
