@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=66, help="block of n x 6n x n cubes (66 = 10M tets, 31 = 1M)")
     ap.add_argument("--quadratic", action="store_true", help="TET10 / 5 Gauss points instead of TET4 / 1")
+    ap.add_argument("--hex", action="store_true", help="HEXAHEDRA8 / 8 Gauss points: one trilinear brick per cube (n x 6n x n bricks)")
     ap.add_argument("--model", default="neohookean", choices=["neohookean", "a5"])
     ap.add_argument("--cpu-sample", type=int, default=None,
                     help="n of the CPU-baseline sample block (0 = skip; default: ~10 s of single-core work, 48 for TET4, 14 for TET10)")
@@ -137,7 +138,7 @@ def main():
     ap.add_argument("--cpu-single-only", action="store_true", help="skip the one-oracle-copy-per-core CPU baseline")
     args = ap.parse_args()
     if args.cpu_sample is None:
-        args.cpu_sample = 14 if args.quadratic else 48
+        args.cpu_sample = 0 if args.hex else 14 if args.quadratic else 48     # (the CPU legs are wired for the tet blocks)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -182,7 +183,7 @@ def main():
     brick = None if args.numbering == "lex" else (4, 2, 2) if args.numbering == "brick" else tuple(int(v) for v in args.numbering.split(","))
     if args.quadratic:
         brick = None
-    deck = mesh.bar_deck(n=args.n, quadratic=args.quadratic, recipe="clamped", model=model, brick=brick,
+    deck = mesh.bar_deck(n=args.n, quadratic=args.quadratic, hexa=args.hex, recipe="clamped", model=model, brick=brick,
                          solver_type=feahip.PCG_ILU, solver_tolerance=1e-14, solver_max_iter=20000)
     free0 = torch.cuda.mem_get_info(local)[0]
     solver = feahip.FeaSolver(deck, device=local)
@@ -254,8 +255,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"{E_total} {'TET10/5GP' if args.quadratic else 'TET4/1GP'} {args.model} block "
-                               f"({args.n}x{6 * args.n}x{args.n} Kuhn cubes on the 1x6x1 bar), "
+        "config": {"workload": f"{E_total} {'HEX8/8GP' if args.hex else 'TET10/5GP' if args.quadratic else 'TET4/1GP'} {args.model} block "
+                               f"({args.n}x{6 * args.n}x{args.n} {'bricks' if args.hex else 'Kuhn cubes'} on the 1x6x1 bar), "
                                f"stiffness+residual assembly, deformed state k1=1.1",
                    "elements": E_total, "nodes": N, "scalar_nnz": nnz, "clock_ramp_launches_before_warmup": RAMP,
                    "sharding": f"block rows in {world} slab(s) across y, ghost elements recomputed, "

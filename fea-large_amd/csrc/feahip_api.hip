@@ -144,7 +144,7 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
   if (n_nodes <= 0 || n_elems <= 0 || !gauss_weights || !dforms || !elements || !nodes0 || !model_params) {
     c->err = "feahip_create: null or empty input"; return FEAHIP_EINVAL;
   }
-  if (npe != 4 && npe != 10) { c->err = "nodes per element must be 4 or 10"; return FEAHIP_EINVAL; }
+  if (npe != 4 && npe != 8 && npe != 10) { c->err = "nodes per element must be 4, 8 or 10"; return FEAHIP_EINVAL; }
   if (gauss_count < 1 || gauss_count > FEA_MAX_GAUSS) { c->err = "gauss_count out of range"; return FEAHIP_EINVAL; }
   if (model != FEAHIP_MODEL_A5 && model != FEAHIP_MODEL_COMPRESSIBLE_NEOHOOKEAN) { c->err = "unknown material model"; return FEAHIP_EINVAL; }
   if (params_count < 2) { c->err = "material needs lambda and mu"; return FEAHIP_EINVAL; }

@@ -384,9 +384,11 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
     if (doK) FEA_HIP_CHECK(c, hipMemsetAsync(c->d_K_base, 0, sizeof(double) * 9 * (size_t)(c->kb1 - c->kb0), c->stream));
     if (doF) FEA_HIP_CHECK(c, hipMemsetAsync(c->d_f, 0, sizeof(double) * (size_t)c->ndof, c->stream));
     if (c->npe == 4) { if (c->linear_tet) launch_atomic_t<4, true>(c, A, doK, doF); else launch_atomic_t<4, false>(c, A, doK, doF); }
+    else if (c->npe == 8) launch_atomic_t<8, false>(c, A, doK, doF);
     else launch_atomic_t<10, false>(c, A, doK, doF);
   } else {
     if (c->npe == 4) { if (c->linear_tet) launch_rowowner_t<4, true>(c, A, doK, doF); else launch_rowowner_t<4, false>(c, A, doK, doF); }
+    else if (c->npe == 8) launch_rowowner_t<8, false>(c, A, doK, doF);
     else launch_rowowner_t<10, false>(c, A, doK, doF);
   }
   FEA_HIP_CHECK(c, hipGetLastError());
@@ -401,7 +403,9 @@ int launch_state_export(feahip_ctx *c, double *d_grads, double *d_detj)
   if (c->npe == 4) {
     if (c->linear_tet) hipLaunchKernelGGL((k_state_export<4, true>), dim3(grid), dim3(256), 0, c->stream, A);
     else hipLaunchKernelGGL((k_state_export<4, false>), dim3(grid), dim3(256), 0, c->stream, A);
-  } else
+  } else if (c->npe == 8)
+    hipLaunchKernelGGL((k_state_export<8, false>), dim3(grid), dim3(256), 0, c->stream, A);
+  else
     hipLaunchKernelGGL((k_state_export<10, false>), dim3(grid), dim3(256), 0, c->stream, A);
   FEA_HIP_CHECK(c, hipGetLastError());
   return FEAHIP_OK;

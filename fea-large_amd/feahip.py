@@ -19,7 +19,7 @@ HOST_LIB_PATH = os.path.join(_HERE, "libfeahost.so")
 MODEL_A5, MODEL_COMPRESSIBLE_NEOHOOKEAN = 0, 1
 CG, PCG_ILU, CHOLESKY = 0, 1, 2
 ASM_AUTO, ASM_ROWOWNER, ASM_ATOMIC, ASM_PATCH, ASM_STAGED, ASM_PAIRED, ASM_PIPELINED, ASM_SHARED, ASM_GATHER = 0, 1, 2, 3, 4, 5, 6, 7, 8
-TETRAHEDRA10, TETRAHEDRA4 = 0, 1
+TETRAHEDRA10, TETRAHEDRA4, HEXAHEDRA8 = 0, 1, 2
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -172,7 +172,7 @@ def _i(a):
 def element_tables(ele_type, gauss_count):
     """(weights[G], forms[G][npe], dforms[G][3][npe]) from the host plug-in."""
     h = load_host_library()
-    npe = 10 if ele_type == TETRAHEDRA10 else 4
+    npe = {TETRAHEDRA10: 10, TETRAHEDRA4: 4, HEXAHEDRA8: 8}[ele_type]
     w = np.zeros(gauss_count)
     forms = np.zeros((gauss_count, npe))
     dforms = np.zeros((gauss_count, 3, npe))

@@ -13,6 +13,8 @@
  * TETRAHEDRA4 (1 point) is a build extension for the BASELINE.json
  * linear-tet configurations: corner shape functions, centroid rule.
  * The 27-point rule is a build extension for BASELINE.json config 5.
+ * HEXAHEDRA8 (trilinear brick on the unit cube, 2 x 2 x 2 Gauss points) is a
+ * build extension for BASELINE.json's "synthetic hex/tet meshes".
  */
 #include <string.h>
 #include "fea_host.h"
@@ -66,6 +68,28 @@ static double t4_N(int i, double r, double s, double t)
 
 static double t4_dN(int i, int d) { return i == 0 ? -1 : (i - 1 == d ? 1 : 0); }
 
+/* 8-node brick on (r,s,t) in [0,1]^3, node k at corner h8_corner[k] (bottom face counter-clockwise, then top) */
+static const int h8_corner[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+
+static double h8_N(int i, double r, double s, double t)
+{
+  const double c[3] = {r, s, t};
+  double v = 1;
+  int d;
+  for (d = 0; d < 3; ++d) v *= h8_corner[i][d] ? c[d] : 1 - c[d];
+  return v;
+}
+
+static double h8_dN(int i, int dd, double r, double s, double t)
+{
+  const double c[3] = {r, s, t};
+  double v = 1;
+  int d;
+  for (d = 0; d < 3; ++d)
+    v *= d == dd ? (h8_corner[i][d] ? 1.0 : -1.0) : (h8_corner[i][d] ? c[d] : 1 - c[d]);
+  return v;
+}
+
 
 /* 27-point rule (3 x 3 x 3 Gauss-Legendre on the unit cube collapsed onto the
  * tetrahedron: r = u, s = v(1-u), t = w(1-u)(1-v), Jacobian (1-u)^2 (1-v)).
@@ -96,9 +120,17 @@ int fea_element_tables(int ele_type, int G, double *weights, double *forms, doub
   int npe, g, i, d;
   if (ele_type == FEA_TETRAHEDRA10) npe = 10;
   else if (ele_type == FEA_TETRAHEDRA4) npe = 4;
+  else if (ele_type == FEA_HEXAHEDRA8) npe = 8;
   else return -1;
   memset(rule, 0, sizeof rule);
-  if (G == 4) {
+  if (ele_type == FEA_HEXAHEDRA8) {
+    const double ga = 0.5 - 0.28867513459481287, gb = 0.5 + 0.28867513459481287;   /* (1 -+ 1/sqrt 3)/2 */
+    if (G != 8) return -1;
+    for (g = 0; g < 8; ++g) {
+      rule[g][0] = 1 / 8.;
+      rule[g][1] = (g & 1) ? gb : ga; rule[g][2] = (g & 2) ? gb : ga; rule[g][3] = (g & 4) ? gb : ga;
+    }
+  } else if (G == 4) {
     for (g = 0; g < 4; ++g) {
       rule[g][0] = (1 / 4.) / 6.;
       rule[g][1] = g == 0 ? a : b; rule[g][2] = g == 1 ? a : b; rule[g][3] = g == 2 ? a : b;
@@ -119,9 +151,9 @@ int fea_element_tables(int ele_type, int G, double *weights, double *forms, doub
     const double r = rule[g][1], s = rule[g][2], t = rule[g][3];
     weights[g] = rule[g][0];
     for (i = 0; i < npe; ++i) {
-      if (forms) forms[g * npe + i] = npe == 10 ? t10_N(i, r, s, t) : t4_N(i, r, s, t);
+      if (forms) forms[g * npe + i] = npe == 10 ? t10_N(i, r, s, t) : npe == 8 ? h8_N(i, r, s, t) : t4_N(i, r, s, t);
       for (d = 0; d < 3; ++d)
-        dforms[(g * 3 + d) * npe + i] = npe == 10 ? t10_dN(i, d, r, s, t) : t4_dN(i, d);
+        dforms[(g * 3 + d) * npe + i] = npe == 10 ? t10_dN(i, d, r, s, t) : npe == 8 ? h8_dN(i, d, r, s, t) : t4_dN(i, d);
     }
   }
   return npe;

@@ -74,6 +74,10 @@ int fea_export_gmsh(const char *filename, const fea_deck *d, const fea_step_snap
       fprintf(f, "%d 11 3 1 1 1 ", i + 1);
       for (j = 0; j < 8; ++j) fprintf(f, "%d ", c[j] + 1);
       fprintf(f, "%d %d \n", c[9] + 1, c[8] + 1);
+    } else if (npe == 8) {                 /* Gmsh type 5, 8-node hexahedron: the same corner order */
+      fprintf(f, "%d 5 3 1 1 1 ", i + 1);
+      for (j = 0; j < 8; ++j) fprintf(f, "%d ", c[j] + 1);
+      fprintf(f, "\n");
     } else {
       fprintf(f, "%d 4 3 1 1 1 ", i + 1);
       for (j = 0; j < 4; ++j) fprintf(f, "%d ", c[j] + 1);

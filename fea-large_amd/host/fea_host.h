@@ -20,7 +20,7 @@ extern "C" {
 
 #define FEA_MAX_MATERIAL_PARAMETERS 10   /* defines.h:22 */
 
-typedef enum { FEA_TETRAHEDRA10 = 0, FEA_TETRAHEDRA4 = 1 } fea_element_type;
+typedef enum { FEA_TETRAHEDRA10 = 0, FEA_TETRAHEDRA4 = 1, FEA_HEXAHEDRA8 = 2 } fea_element_type;
 
 /* fea_task + fea_solution_params + the three input arrays of the reference
  * (fea_solver.h:94-155), as one flat record                                 */

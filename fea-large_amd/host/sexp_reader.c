@@ -297,6 +297,7 @@ static int read_list(reader *r, fea_deck *d)
     if (!(s = attr_get(a, na, "name"))) return fail(r, "missing attribute :name");
     if (ieq(s, "TETRAHEDRA10")) d->ele_type = FEA_TETRAHEDRA10;
     else if (ieq(s, "TETRAHEDRA4")) d->ele_type = FEA_TETRAHEDRA4;   /* build extension */
+    else if (ieq(s, "HEXAHEDRA8")) d->ele_type = FEA_HEXAHEDRA8;     /* build extension */
     else { char m[TOK_MAX + 32]; snprintf(m, sizeof m, "unknown element type '%s'", s); return fail(r, m); }
   } else if (ieq(head, "line-search")) {                      /* :157-163 */
     if (need_num(r, a, na, "max", &v)) return -1;
@@ -387,7 +388,7 @@ int fea_deck_save(const char *path, const fea_deck *d)
              " :modified-newton %s :max-newton-count %d\n",
           d->desired_tolerance, d->load_increments_count, d->modified_newton ? "yes" : "no", d->max_newton_count);
   fprintf(f, "   (element-type :gauss-nodes-count %d :name %s :nodes-count %d)\n", d->gauss_nodes_count,
-          d->ele_type == FEA_TETRAHEDRA4 ? "TETRAHEDRA4" : "TETRAHEDRA10", d->nodes_per_element);
+          d->ele_type == FEA_TETRAHEDRA4 ? "TETRAHEDRA4" : d->ele_type == FEA_HEXAHEDRA8 ? "HEXAHEDRA8" : "TETRAHEDRA10", d->nodes_per_element);
   fprintf(f, "   (slae-solver :type %s :tolerance %.17g :max-iterations %d)\n", solver[d->solver_type],
           d->solver_tolerance, d->solver_max_iter);
   fprintf(f, "   (line-search :max %d)\n   (arc-length :max %d))\n", d->linesearch_max, d->arclength_max);

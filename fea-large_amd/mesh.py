@@ -21,7 +21,7 @@ import math
 
 import numpy as np
 
-from feahip import (CG, MODEL_COMPRESSIBLE_NEOHOOKEAN, TETRAHEDRA4, TETRAHEDRA10, Deck)
+from feahip import (CG, HEXAHEDRA8, MODEL_COMPRESSIBLE_NEOHOOKEAN, TETRAHEDRA4, TETRAHEDRA10, Deck)
 
 _EDGES = [(0, 1), (1, 2), (0, 2), (0, 3), (1, 3), (2, 3)]
 
@@ -57,12 +57,9 @@ def brick_numbering(gx, gy, gz, brick):
     i, k, j = ids % gx, (ids // gx) % gz, ids // (gx * gz)
     bi, bk, bj = i // bx, k // bz, j // by
     li, lk, lj = i % bx, k % bz, j % by
-    wx = np.minimum(bx, gx - bi * bx)                  # the last brick along an axis may be thinner
-    wz = np.minimum(bz, gz - bk * bz)
     key = np.lexsort((li, lk, lj, bi, bk, bj))           # last key is the slowest
     new_id = np.empty_like(ids)
     new_id[key] = ids
-    del wx, wz
     return new_id
 
 
@@ -94,6 +91,34 @@ def kuhn_block(nx, ny, nz, quadratic=False, origin=(0.0, 1.0, 0.0), size=(1.0, 6
     nodes[:, 0] = origin[0] + size[0] * i.ravel() / (gx - 1)
     nodes[:, 1] = origin[1] + size[1] * j.ravel() / (gy - 1)
     nodes[:, 2] = origin[2] + size[2] * k.ravel() / (gz - 1)
+    if brick is not None:
+        new_id = brick_numbering(gx, gy, gz, brick)
+        elements = new_id[elements].astype(np.int32)
+        out = np.empty_like(nodes)
+        out[new_id] = nodes
+        nodes = out
+    return nodes, elements
+
+
+def hex_block(nx, ny, nz, origin=(0.0, 1.0, 0.0), size=(1.0, 6.0, 1.0), brick=None):
+    """(nodes[N][3], elements[E][8]) of the block as one trilinear brick per cube (BASELINE.json's "synthetic hex
+    meshes"; the reference has tetrahedra only).  Corner order of fea_elements.c: bottom face counter-clockwise seen
+    from +t, then the top face; local axes (r, s, t) = (x, y, z), so every Jacobian is positive."""
+    gx, gy, gz = nx + 1, ny + 1, nz + 1
+
+    def nid(i, j, k):                  # x fastest, then z, y slowest (as kuhn_block)
+        return (j * gz + k) * gx + i
+
+    ci, cj, ck = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    order = np.lexsort((ci.ravel(), ck.ravel(), cj.ravel()))
+    i, j, k = ci.ravel()[order], cj.ravel()[order], ck.ravel()[order]
+    corners = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]
+    elements = np.stack([nid(i + a, j + b, k + c) for (a, b, c) in corners], axis=1).astype(np.int32)
+    jj, kk, ii = np.meshgrid(np.arange(gy), np.arange(gz), np.arange(gx), indexing="ij")
+    nodes = np.empty((gx * gy * gz, 3))
+    nodes[:, 0] = origin[0] + size[0] * ii.ravel() / (gx - 1)
+    nodes[:, 1] = origin[1] + size[1] * jj.ravel() / (gy - 1)
+    nodes[:, 2] = origin[2] + size[2] * kk.ravel() / (gz - 1)
     if brick is not None:
         new_id = brick_numbering(gx, gy, gz, brick)
         elements = new_id[elements].astype(np.int32)
@@ -140,8 +165,16 @@ def increment_for(n):
 
 
 def bar_deck(n=None, dims=None, quadratic=False, recipe="clamped", model=MODEL_COMPRESSIBLE_NEOHOOKEAN,
-             gauss=None, dy=None, brick=None, **kw):
+             gauss=None, dy=None, brick=None, hexa=False, **kw):
     nx, ny, nz = dims if dims is not None else block_dims(n)
+    if hexa:
+        nodes, elements = hex_block(nx, ny, nz, brick=brick)
+        if dy is None:
+            dy = increment_for(max(nx, nz))
+        ids, types, vals = bar_boundary(nodes, recipe, dy)
+        kw.setdefault("solver_type", CG)
+        return Deck(model=model, parameters=[100.0, 100.0], ele_type=HEXAHEDRA8, gauss_nodes_count=8 if gauss is None else gauss,
+                    nodes=nodes, elements=elements, presc_node=ids, presc_type=types, presc_values=vals, **kw)
     nodes, elements = kuhn_block(nx, ny, nz, quadratic, brick=brick)
     if dy is None:
         dy = increment_for(max(nx, nz))

@@ -275,6 +275,44 @@ static double tet4_dform(int i, int d, double r, double s, double t)
 }
 
 
+/* trilinear 8-node hexahedron on the unit cube (r,s,t) in [0,1]^3: build
+ * extension (BASELINE.json's "synthetic hex/tet meshes"; the reference has
+ * tetrahedra only, fea_solver.h:68-71).  Node k sits at corner
+ * (cx,cy,cz)[k], the usual counter-clockwise bottom face then top face; it
+ * goes through the same generic loops (isoform / disoform tables,
+ * fea_solver.c:503-535), with the 2 x 2 x 2 Gauss rule (weights 1/8: the
+ * reference's rules carry the volume of the parent element too, :26-28).    */
+static const int hex8_corner[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+
+static double hex8_form(int i, double r, double s, double t)
+{
+  const double c[3] = {r, s, t};
+  double v = 1;
+  int d;
+  for (d = 0; d < 3; ++d) v *= hex8_corner[i][d] ? c[d] : 1 - c[d];
+  return v;
+}
+
+static double hex8_dform(int i, int dd, double r, double s, double t)
+{
+  const double c[3] = {r, s, t};
+  double v = 1;
+  int d;
+  for (d = 0; d < 3; ++d)
+    v *= d == dd ? (hex8_corner[i][d] ? 1.0 : -1.0) : (hex8_corner[i][d] ? c[d] : 1 - c[d]);
+  return v;
+}
+
+static void rule8_orc(double rule[27][4])
+{
+  const double a = 0.5 - 0.28867513459481287, b = 0.5 + 0.28867513459481287;      /* (1 -+ 1/sqrt 3)/2 */
+  int n;
+  for (n = 0; n < 8; ++n) {
+    rule[n][0] = 1. / 8.;
+    rule[n][1] = (n & 1) ? b : a; rule[n][2] = (n & 2) ? b : a; rule[n][3] = (n & 4) ? b : a;
+  }
+}
+
 /* 27-point rule (3 x 3 x 3 Gauss-Legendre on the unit cube collapsed onto the
  * tetrahedron: r = u, s = v(1-u), t = w(1-u)(1-v), Jacobian (1-u)^2 (1-v)).
  * Not in the reference (it stops at 5 points, fea_solver.c:1495-1504);
@@ -326,6 +364,10 @@ int orc_elem_table_init(orc_elem_table *tb, int kind, int ngauss)
     else if (ngauss == 4) gd = g4;
     else if (ngauss == 5) gd = g5;
     else return -1;
+  } else if (kind == ORC_HEX8) {
+    tb->npe = 8;
+    if (ngauss == 8) { rule8_orc(g27); gd = g27; }
+    else return -1;
   } else
     return -1;
   tb->ngauss = ngauss;
@@ -335,10 +377,10 @@ int orc_elem_table_init(orc_elem_table *tb, int kind, int ngauss)
     tb->weight[g] = gd[g][0];
     for (i = 0; i < tb->npe; ++i) {
       tb->forms[g][i] = kind == ORC_TET10 ? tet10_form(i, r, s, t)
-                                          : tet4_form(i, r, s, t);
+                        : kind == ORC_HEX8 ? hex8_form(i, r, s, t) : tet4_form(i, r, s, t);
       for (j = 0; j < 3; ++j)
         tb->dforms[g][j][i] = kind == ORC_TET10 ? tet10_dform(i, j, r, s, t)
-                                                : tet4_dform(i, j, r, s, t);
+                              : kind == ORC_HEX8 ? hex8_dform(i, j, r, s, t) : tet4_dform(i, j, r, s, t);
     }
   }
   return 0;

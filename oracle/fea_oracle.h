@@ -44,7 +44,7 @@ extern "C" {
 
 /* element kinds: TET10 is the reference's; the others are build extensions
  * that run through the same generic loops            */
-enum { ORC_TET10 = 0, ORC_TET4 = 1 };
+enum { ORC_TET10 = 0, ORC_TET4 = 1, ORC_HEX8 = 2 };
 /* material models, numbered as fea_model.h:37-40 */
 enum { ORC_MODEL_A5 = 0, ORC_MODEL_NEOHOOKEAN = 1 };
 /* linear solvers, numbered as fea_solver.h:62-66 */

@@ -17,7 +17,7 @@ _ip = C.POINTER(C.c_int)
 M33 = (C.c_double * 3) * 3
 C4 = (((C.c_double * 3) * 3) * 3) * 3
 
-TET10, TET4 = 0, 1
+TET10, TET4, HEX8 = 0, 1, 2
 
 
 class BcNode(C.Structure):
@@ -132,7 +132,7 @@ class OracleSolver:
         self.N, self.E = len(deck.nodes), len(deck.elements)
         self.npe, self.G = deck.nodes_per_element, deck.gauss_nodes_count
         self.ndof = 3 * self.N
-        kind = TET10 if self.npe == 10 else TET4
+        kind = {10: TET10, 4: TET4, 8: HEX8}[self.npe]
         nb = len(deck.presc_node)
         bc = (BcNode * max(nb, 1))()
         for i in range(nb):

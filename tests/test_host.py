@@ -100,7 +100,8 @@ def test_deck_roundtrip(tmp_path):
 
 
 @pytest.mark.parametrize("ele,kind,G", [(feahip.TETRAHEDRA10, ob.TET10, 4), (feahip.TETRAHEDRA10, ob.TET10, 5),
-                                        (feahip.TETRAHEDRA10, ob.TET10, 27), (feahip.TETRAHEDRA4, ob.TET4, 1)])
+                                        (feahip.TETRAHEDRA10, ob.TET10, 27), (feahip.TETRAHEDRA4, ob.TET4, 1),
+                                        (feahip.HEXAHEDRA8, ob.HEX8, 8)])
 def test_element_tables_equal_oracle_bitwise(ele, kind, G):
     w, forms, dforms = feahip.element_tables(ele, G)
     ow, oforms, odforms = ob.elem_table(kind, G)
