@@ -221,8 +221,8 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
 // shared-state assembly of 10-node elements (kernels_quad.hip): per chunk the
 // distinct elements touching its rows and one 4-byte record per
 // (row, element, column node) pair
-#define FEA_QUAD_BLOCKS 128           // K tile of one workgroup
-#define FEA_QUAD_PAIRS 256            // pairs of a multi-row chunk (a single row may have more)
+#define FEA_QUAD_BLOCKS 256           // K tile of one workgroup (tile position: 8 bits of the pair word)
+#define FEA_QUAD_PAIRS 512            // pairs of a multi-row chunk (a single row may have more)
 #define FEA_QUAD_ELEMS 64             // distinct elements of a chunk (6-bit index in a pair record)
 #define FEA_QUAD_NODES 126            // coordinate tile: distinct nodes of the chunk's elements
 #define FEA_QUAD_VISITS 96            // (row, element) visits of a chunk: one row-vector record per visit and Gauss point of a batch
