@@ -6,8 +6,9 @@
  *
  * One option the reference does not have, after the deck name:
  *   --multigrid   PCG_ILU / CHOLESKY solves use the aggregation-multigrid
- *                 preconditioner (feahip_set_preconditioner); ignored with a
- *                 note when the mesh is too small to coarsen.
+ *                 preconditioner (feahip_set_preconditioner); an error, not a
+ *                 silent return to block-Jacobi, when the mesh is too small
+ *                 to coarsen.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -35,8 +36,13 @@ int main(int argc, char **argv)
     fea_deck_free(&deck);
     return 1;
   }
-  if (argc > 2 && strcmp(argv[2], "--multigrid") == 0 && feahip_set_preconditioner(ctx, 1))
-    printf("multigrid preconditioner not used: %s\n", feahip_last_error(ctx));
+  if (argc > 2 && strcmp(argv[2], "--multigrid") == 0 && feahip_set_preconditioner(ctx, 1)) {
+    /* asked for and not available: say so and stop, never run another preconditioner in its place */
+    fprintf(stderr, "feasolve error encountered: --multigrid: %s\n", feahip_last_error(ctx));
+    feahip_destroy(ctx);
+    fea_deck_free(&deck);
+    return 1;
+  }
   cap = deck.load_increments_count > 0 ? deck.load_increments_count : 1;
   steps = (fea_step_snapshot *)calloc((size_t)cap, sizeof *steps);
   done = fea_solve_with_snapshots(&deck, ctx, stdout, steps, deck.load_increments_count);

@@ -209,7 +209,34 @@ def test_10m_assembly_properties():
     s.set_assembly(feahip.ASM_STAGED)
     s.create_stiffness_and_residual()
     yb = s.spmv(a)
-    s.set_row_shard(5, 8)
+    s.set_row_shard(3, 8)
+    assert s.owned_rows() == (r0, r1)
     s.create_stiffness_and_residual()
     assert np.array_equal(s.spmv(a)[3 * r0:3 * r1], yb[3 * r0:3 * r1])
+    s.close()
+
+
+def test_10m_a5_cylinder_properties():
+    """configs[3] at its full size on one device: the Lame cylinder (r in [1,2], z in [-8,8], exact-solutions/lame)
+    as 64 x 104 x 256 cells of the (r, axial, theta) block = 10 223 616 linear tets, model A5.  One assembly in the
+    bumped state, checked by size-independent properties: no inverted element, K symmetric, K . (axial translation)
+    = 0, f = 0 at the reference state; and one rank of 8 assembles its rows like the unsharded run."""
+    deck = mesh.cylinder_deck(64, 256, 104)
+    assert len(deck.elements) == 64 * 256 * 104 * 6 == 10223616
+    s = feahip.FeaSolver(deck)
+    s.create_residual_forces()
+    assert np.abs(s.forces()).max() < 1e-10
+    s.update_nodes_with_bc(1.0)
+    s.create_stiffness_and_residual()
+    assert s.update_state() == 0
+    rng = np.random.default_rng(23)
+    a, b = rng.normal(size=s.ndof), rng.normal(size=s.ndof)
+    ya = s.spmv(a)
+    t = np.zeros(s.ndof); t[2::3] = 1.0
+    assert np.abs(s.spmv(t)).max() < 1e-11 * np.abs(ya).max()
+    assert abs(b @ ya - a @ s.spmv(b)) < 1e-11 * abs(b @ ya)
+    s.set_row_shard(6, 8)
+    r0, r1 = s.owned_rows()
+    s.create_stiffness_and_residual()
+    assert np.abs(s.spmv(a)[3 * r0:3 * r1] - ya[3 * r0:3 * r1]).max() < 1e-13 * np.abs(ya).max()
     s.close()

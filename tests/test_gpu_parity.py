@@ -556,10 +556,11 @@ def test_feasolver_hip_command_line(decks_dir, tmp_path):
     last = [i for i, l in enumerate(msh) if l == "$NodeData"][-1]
     row = msh[last + 9 + top].split()
     assert int(row[0]) == top + 1 and float(row[2]) == pytest.approx(0.1, abs=1e-6)
-    # the one extra option: on this 737-node deck the multigrid is refused with a note and the run is the same
+    # the one extra option: on this 737-node deck there is nothing to coarsen -- asked for and unavailable is an error
+    # (exit code 1, message), never a quiet run with another preconditioner
     res2 = subprocess.run([exe, str(deckfile), "--multigrid"], capture_output=True, text=True, timeout=300)
-    assert res2.returncode == 0 and "multigrid preconditioner not used" in res2.stdout
-    assert res2.stdout.count("Newton iteration") == 25
+    assert res2.returncode == 1 and "--multigrid" in res2.stderr and "multigrid" in res2.stderr
+    assert res2.stdout.count("Newton iteration") == 0                  # no quiet run with another preconditioner
 
 
 def test_node_with_more_neighbours_than_the_spmv_tile():
