@@ -541,3 +541,26 @@ extern "C" int feahip_host_assembly_digest(int n_nodes, int n_elems, int npe, co
   }
   return FEAHIP_OK;
 }
+
+#ifdef FEAHIP_DEBUG
+// diagnostic build only, host only: one chunk's map record and the layout, for the LDS bank model (dbg/lds_model.py)
+extern "C" int feahip_debug_gather_record_host(int n_nodes, int n_elems, const int *elements, int chunk, int *layout_ints,
+                                               unsigned char *record, int *nchunks)
+{
+  static HostGather hg;                       // cached between the sizing call and the copying call
+  static int cached_n = -1, cached_e = -1;
+  if (cached_n != n_nodes || cached_e != n_elems) {
+    HostPattern hp;
+    std::string err;
+    if (build_host_pattern(n_nodes, n_elems, 4, elements, hp, err)) return FEAHIP_EINVAL;
+    build_host_gather(n_nodes, n_elems, elements, hp, 0, n_nodes, hg);
+    if (!hg.ok) return FEAHIP_EINVAL;
+    cached_n = n_nodes; cached_e = n_elems;
+  }
+  if (chunk < 0) chunk = hg.nchunks / 2;
+  memcpy(layout_ints, &hg.lay, sizeof(GatherLayout));
+  if (nchunks) *nchunks = hg.nchunks;
+  if (record) memcpy(record, hg.blob.data() + (size_t)chunk * hg.lay.stride, hg.lay.stride);
+  return (int)(sizeof(GatherLayout) / sizeof(int));
+}
+#endif

@@ -147,18 +147,24 @@ __device__ __forceinline__ void g_visit(const double *sT, unsigned w, double (&f
 }
 
 // logical record R = { g[4][3], t[4][3], vl, vm } (or { s[4][3] }) -> the piece layout above
+// two doubles of a record -> LDS with one ds_write2_b64: the instruction takes its two operands from ANY two register
+// pairs, whereas the ds_write_b128 the compiler forms out of adjacent stores needs four consecutive registers and cost
+// 47 v_mov_b64 per record to pack them.  Inline asm: the compiler does not see these stores, so the caller waits for
+// them itself (G_LDS_DRAIN) before the barrier.
+#define G_W2(addr, a, b, o) asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(addr), "v"(a), "v"(b), "n"(o), "n"((o) + 1) : "memory")
+#define G_LDS_DRAIN() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
 template <bool DOK>
 __device__ __forceinline__ void g_store_record(double *dst, const double *R)
 {
-  double2 *o = reinterpret_cast<double2 *>(dst);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) o[k] = make_double2(R[3 * k], R[3 * k + 1]);
+  const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)dst;
+  G_W2(a, R[0], R[1], 0); G_W2(a, R[3], R[4], 2); G_W2(a, R[6], R[7], 4); G_W2(a, R[9], R[10], 6);
   if (DOK) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { o[4 + k] = make_double2(R[12 + 3 * k], R[12 + 3 * k + 1]); o[8 + k] = make_double2(R[3 * k + 2], R[12 + 3 * k + 2]); }
-    o[12] = make_double2(R[24], R[25]);
+    G_W2(a, R[12], R[13], 8); G_W2(a, R[15], R[16], 10); G_W2(a, R[18], R[19], 12); G_W2(a, R[21], R[22], 14);
+    G_W2(a, R[2], R[14], 16); G_W2(a, R[5], R[17], 18); G_W2(a, R[8], R[20], 20); G_W2(a, R[11], R[23], 22);
+    G_W2(a, R[24], R[25], 24);
   } else {
-    o[4] = make_double2(R[2], R[5]); o[5] = make_double2(R[8], R[11]);
+    G_W2(a, R[2], R[5], 8); G_W2(a, R[8], R[11], 10);
   }
 }
 
@@ -421,17 +427,19 @@ void k_assemble_gather(GatherArgs A, int run_len)
           const int g0 = min(min(gn[nd[0]], gn[nd[1]]), min(gn[nd[2]], gn[nd[3]]));
           if (g0 >= h.r0 && g0 < h.r1) atomicAdd(A.bad, 1);
         }
-        if (detJ == 0.0) {                             // fea_solver.c:697: no gradient, no contribution
-#pragma unroll
-          for (int q = 0; q < REC; ++q) R[q] = 0.0;
-        }
       }
-      if (!G_ABL(1)) g_store_record<DOK>(sT + t * REC, R); else sT[t * REC] = R[0] + R[25 % REC];
+      if (detJ == 0.0) {                               // fea_solver.c:697: no gradient, no contribution: an all-zero record
+        double2 *o = reinterpret_cast<double2 *>(sT + t * REC);
+#pragma unroll
+        for (int q = 0; q < REC / 2; ++q) o[q] = make_double2(0.0, 0.0);
+      } else if (!G_ABL(1)) g_store_record<DOK>(sT + t * REC, R);
+      else sT[t * REC] = R[0] + R[25 % REC];
     } else if (t < h.nelem) {                          // unused slot: the all-zero record empty list slots point at
       double2 *o = reinterpret_cast<double2 *>(sT + t * REC);
 #pragma unroll
       for (int q = 0; q < REC / 2; ++q) o[q] = make_double2(0.0, 0.0);
     }
+    G_LDS_DRAIN();                                     // the asm record stores
     G_BARRIER();                                       // records visible; the coordinate tile is dead
     G_STAMP(1);
 
