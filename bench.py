@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--no-newton", action="store_true", help="skip the single full Newton iteration")
     ap.add_argument("--assembly", default="auto", help="assembly strategy: auto | gather | staged | ... (fea_hip.h)")
     ap.add_argument("--numbering", default="brick", help="node numbering of the synthetic block: 'brick' = bricks of "
-                    "4x2x2 nodes (SURVEY 8d allows a locality numbering), 'lex' = x fastest, z, y slowest, or bx,by,bz")
+                    "4x2x2 nodes, 3x4x4 half-grid nodes with --quadratic (SURVEY 8d allows a locality numbering), 'lex' = x fastest, z, y slowest, or bx,by,bz")
     ap.add_argument("--cpu-single-only", action="store_true", help="skip the one-oracle-copy-per-core CPU baseline")
     args = ap.parse_args()
     if args.cpu_sample is None:
@@ -180,9 +180,10 @@ def main():
             dist.barrier()
 
     t_setup = time.perf_counter()
-    brick = None if args.numbering == "lex" else (4, 2, 2) if args.numbering == "brick" else tuple(int(v) for v in args.numbering.split(","))
-    if args.quadratic:
-        brick = None
+    # 'brick': 4x2x2 nodes for the corner-node meshes, 3x4x4 nodes of the half-spacing grid for 10-node tetrahedra (48
+    # rows: one gather chunk of kernels_gather10.hip)
+    brick = (None if args.numbering == "lex" else ((3, 4, 4) if args.quadratic else (4, 2, 2)) if args.numbering == "brick"
+             else tuple(int(v) for v in args.numbering.split(",")))
     deck = mesh.bar_deck(n=args.n, quadratic=args.quadratic, hexa=args.hex, recipe="clamped", model=model, brick=brick,
                          solver_type=feahip.PCG_ILU, solver_tolerance=1e-14, solver_max_iter=20000)
     free0 = torch.cuda.mem_get_info(local)[0]
@@ -200,7 +201,7 @@ def main():
     t_setup = time.perf_counter() - t_setup
     dev_bytes = free0 - torch.cuda.mem_get_info(local)[0]
     in_use = solver.assembly_in_use()
-    kernel = {feahip.ASM_GATHER: "k_assemble_gather", feahip.ASM_STAGED: "k_assemble_visit", feahip.ASM_PIPELINED: "k_assemble_run",
+    kernel = {feahip.ASM_GATHER: "k_assemble_gather10" if args.quadratic else "k_assemble_gather", feahip.ASM_STAGED: "k_assemble_visit", feahip.ASM_PIPELINED: "k_assemble_run",
               feahip.ASM_SHARED: "k_assemble_quad", feahip.ASM_PATCH: "k_assemble_patch", feahip.ASM_PAIRED: "k_assemble_pair",
               feahip.ASM_ATOMIC: "k_assemble_atomic"}.get(in_use, "k_assemble_rowowner")
 

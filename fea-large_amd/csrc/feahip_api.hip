@@ -280,7 +280,8 @@ extern "C" void feahip_destroy(feahip_ctx *c)
   if (!c) return;
   delete c->h_pat; c->h_pat = nullptr;
   delete c->gather_lay; c->gather_lay = nullptr;
-  void *ptrs[] = {(void *)c->d_gmaps, c->d_table, c->d_conn, c->d_X0, c->d_x, c->d_rowptr, c->d_colidx, c->d_K_base, c->d_Kstash_base,
+  delete c->gather10_lay; c->gather10_lay = nullptr;
+  void *ptrs[] = {(void *)c->d_gmaps, (void *)c->d_g10_elist, (void *)c->d_g10_state, c->d_table, c->d_conn, c->d_X0, c->d_x, c->d_rowptr, c->d_colidx, c->d_K_base, c->d_Kstash_base,
                   c->d_incptr, c->d_inc, c->d_incslot, c->d_chunk, c->d_diag, c->d_pdesc, c->d_pnode, c->d_pelem, c->d_pent, c->d_pbptr, c->d_vdesc, c->d_vnode, c->d_vrec, c->d_pairdesc, c->d_prec, c->d_qdesc, c->d_qelem, c->d_qpair, c->d_qnode, c->d_f, c->d_u, c->d_r, c->d_p,
                   c->d_q, c->d_minv, c->d_part, c->d_scal, c->d_flag, c->d_cdof, c->d_cval,
                   c->d_dofmask, c->d_F, c->d_S};

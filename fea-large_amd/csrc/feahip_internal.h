@@ -104,6 +104,11 @@ struct feahip_ctx {
   struct GatherLayout *gather_lay = nullptr;
   long long gather_bytes = 0;
   double gather_evals_per_element = 0;   // element evaluations the gather chunks make per element this rank touches
+  // the same for 10-node tetrahedra (kernels_gather10.hip); shares d_gmaps / ngchunks / gather_row0.. with the above
+  struct Gather10Layout *gather10_lay = nullptr;
+  int *d_g10_elist = nullptr;            // this rank's elements
+  double *d_g10_state = nullptr;         // [elements of the rank][G][18]: Gauss-point state records (kernels_gather10.hip)
+  int g10_nloc = 0;
   bool have_pairs = false;
   struct VisitDesc *d_pairdesc = nullptr;
   uint32_t *d_prec = nullptr;
@@ -276,6 +281,46 @@ struct HostGather {
 void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int row_lo, int row_hi, HostGather &out);
 int ensure_gather(feahip_ctx *c);
 int launch_assemble_gather(feahip_ctx *c, bool doK, bool doF);
+
+// GATHER assembly of 10-node tetrahedra (kernels_gather10.hip, gather10.cpp).  Same idea as the 4-node one with the
+// Gauss points as an outer loop: a 256-thread workgroup owns up to 64 consecutive block rows, evaluates every
+// distinct element touching them once per Gauss point into LDS records (spatial gradient g_k and traction vector
+// t_k of its ten nodes), and every thread sums up to five off-diagonal blocks over all Gauss points in registers.
+#define FEA_Q_THREADS 256
+#define FEA_Q_MAX_ROWS 64
+#define FEA_Q_MAX_NODES 240           // 8-bit chunk-local node ids
+#define FEA_Q_MAX_ELEMS 127           // 7-bit record slot; the slot after the last one in use is the all-zero record
+#define FEA_Q_SLOTS 5                 // blocks per thread
+#define FEA_Q_REGW 4                  // contribution words per block a thread keeps in registers (2 entries each)
+#define FEA_Q_MAX_PASS 7              // write-out passes of one chunk through the K tile
+#define FEA_Q_FLANES 128              // residual lanes (the last two waves)
+#define FEA_Q_ROWS_U16 200            // rstart[65] | rdiag[64] at 66 | ffirst[65] at 130
+struct Gather10Header {              // 128 bytes
+  int r0, r1, b0, nb;
+  int nnode, nelem, ntask, npass;
+  int nft, fdw;                      // residual lanes, words per residual lane (2 visits each)
+  unsigned char prow[8];             // pass p writes the rows [prow[p], prow[p+1]) of the chunk
+  unsigned char cnt[FEA_Q_SLOTS * 4];// contributions of the longest list among the 64 blocks wave w holds in slot s, at [4 s + w]
+  unsigned char sw[8];               // list words stored for slot s (the longest of its four waves); rows of the clist section
+  int pad[13];
+};
+struct Gather10Layout {
+  int stride;
+  int o_nodes, o_elems, o_rows, o_tpos, o_flist, o_clist;
+  int max_nodes, max_elems, max_cw, max_fdw, tile_blocks;      // max_cw: clist rows (256 words each) of the longest chunk
+};
+struct HostGather10 {
+  Gather10Layout lay;
+  std::vector<unsigned char> blob;
+  std::vector<int> first_row;
+  std::vector<int> elist;            // the rank's elements (touching its rows), ascending: order of the state records
+  long long total_evals = 0, distinct_elems = 0;
+  int nchunks = 0;
+  bool ok = false;
+};
+void build_host_gather10(int N, int E, const int *conn, const HostPattern &hp, int row_lo, int row_hi, HostGather10 &out);
+int ensure_gather10(feahip_ctx *c);
+int launch_assemble_gather10(feahip_ctx *c, bool doF);
 
 struct HostPairs {
   std::vector<VisitDesc> desc;       // visit_off / nvisit = first pair / pairs of the chunk

@@ -495,6 +495,18 @@ void gather_row_digest(const HostGather &hg, const HostPattern &hp, unsigned lon
   }
 }
 
+void gather10_row_digest(const HostGather10 &hg, const HostPattern &hp, const int *conn, unsigned long long *rowhash,
+                         unsigned long long (*hash)(int, int, const int *, int, int));     // gather10.cpp
+namespace {
+unsigned long long contribution_hash10(int a, int b, const int *g, int la, int lb)
+{
+  unsigned long long h = 0x1234567ull;
+  h = mix(h, (unsigned long long)a); h = mix(h, (unsigned long long)b);
+  for (int k = 0; k < 10; ++k) h = mix(h, (unsigned long long)g[k]);
+  return mix(h, (unsigned long long)(la * 16 + lb));
+}
+}  // namespace
+
 void quad_row_digest(const HostQuad &hq, const HostPattern &hp, unsigned long long *rowhash)
 {
   for (const QuadDesc &d : hq.desc) {
@@ -530,14 +542,28 @@ extern "C" int feahip_host_assembly_digest(int n_nodes, int n_elems, int npe, co
     if (!hg.ok) return FEAHIP_EINVAL;
     gather_row_digest(hg, hp, rowhash);
   } else {
-    if (hp.super_achunk.empty()) return FEAHIP_EINVAL;
-    const int nchunks = (int)hp.chunk.size() - 1;
-    const int nsuper = (nchunks + FEA_SUPER_CHUNKS - 1) / FEA_SUPER_CHUNKS;
-    const int s0 = (int)((long long)nsuper * rank / nranks), s1 = (int)((long long)nsuper * (rank + 1) / nranks);
-    HostQuad hq;
-    build_host_quad(n_nodes, n_elems, npe, elements, hp, hp.super_achunk[s0], hp.super_achunk[s1], hq);
-    if (!hq.ok) return FEAHIP_EINVAL;
-    quad_row_digest(hq, hp, rowhash);
+    // what AUTO runs for 10-node elements (kernels_assemble.hip): the gather maps when they build and an element
+    // is not evaluated by too many chunks, the shared-state maps otherwise.  Both list every off-diagonal
+    // contribution (the gather maps' mirror blocks are expanded); neither digest covers the diagonal blocks.
+    bool done = false;
+    if (npe == 10) {
+      HostGather10 hg;
+      build_host_gather10(n_nodes, n_elems, elements, hp, row0, row1, hg);
+      if (hg.ok && (double)hg.total_evals <= 6.0 * (double)hg.distinct_elems) {
+        gather10_row_digest(hg, hp, elements, rowhash, contribution_hash10);
+        done = true;
+      }
+    }
+    if (!done) {
+      if (hp.super_achunk.empty()) return FEAHIP_EINVAL;
+      const int nchunks = (int)hp.chunk.size() - 1;
+      const int nsuper = (nchunks + FEA_SUPER_CHUNKS - 1) / FEA_SUPER_CHUNKS;
+      const int s0 = (int)((long long)nsuper * rank / nranks), s1 = (int)((long long)nsuper * (rank + 1) / nranks);
+      HostQuad hq;
+      build_host_quad(n_nodes, n_elems, npe, elements, hp, hp.super_achunk[s0], hp.super_achunk[s1], hq);
+      if (!hq.ok) return FEAHIP_EINVAL;
+      quad_row_digest(hq, hp, rowhash);
+    }
   }
   return FEAHIP_OK;
 }

@@ -319,6 +319,12 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
         if (c->have_visits) strat = FEAHIP_ASM_STAGED;
       }
     }
+    if (strat == FEAHIP_ASM_AUTO && c->npe == 10 && doK) {
+      // 10-node tetrahedra: gather chunks of up to 32 rows where the numbering keeps them compact (an element is
+      // evaluated ~3 times with a brick numbering, 8 times by the 3-row chunks of the shared-state kernel)
+      { const int rc = ensure_gather10(c); if (rc) return rc; }
+      if (c->have_gather && c->gather_evals_per_element <= 6.0) strat = FEAHIP_ASM_GATHER;
+    }
     if (strat == FEAHIP_ASM_AUTO && c->npe == 10) { const int rc = ensure_quad(c); if (rc) return rc; }
     if (strat == FEAHIP_ASM_AUTO)
       strat = (c->have_quad && doK) ? FEAHIP_ASM_SHARED : (rowowner_ok ? FEAHIP_ASM_ROWOWNER : FEAHIP_ASM_ATOMIC);
@@ -333,6 +339,18 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
     }
     FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));
     return launch_assemble_quad(c, doF);
+  }
+  if (strat == FEAHIP_ASM_GATHER && c->npe == 10) {
+    { const int rc = ensure_gather10(c); if (rc) return rc; }
+    if (!c->have_gather) {
+      c->err = "gather assembly of 10-node tetrahedra needs rows that fit the LDS tiles";
+      return FEAHIP_EINVAL;
+    }
+    if (!doK) strat = rowowner_ok ? FEAHIP_ASM_ROWOWNER : FEAHIP_ASM_ATOMIC;      // residual alone: visit kernel
+    else {
+      FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));
+      return launch_assemble_gather10(c, doF);
+    }
   }
   if (strat == FEAHIP_ASM_GATHER) {
     { const int rc = ensure_gather(c); if (rc) return rc; }

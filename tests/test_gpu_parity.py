@@ -39,7 +39,7 @@ def check_assembly(s, o, strategies=(feahip.ASM_ROWOWNER, feahip.ASM_ATOMIC)):
     if s.npe == 4 and s.G == 1:
         strategies = tuple(strategies) + (feahip.ASM_PATCH, feahip.ASM_STAGED, feahip.ASM_PAIRED, feahip.ASM_PIPELINED, feahip.ASM_GATHER)
     if s.npe == 10:
-        strategies = tuple(strategies) + (feahip.ASM_SHARED,)
+        strategies = tuple(strategies) + (feahip.ASM_SHARED, feahip.ASM_GATHER)
     o.update_state()
     o.create_stiffness()
     o.create_residual_forces()

@@ -231,18 +231,18 @@ def test_host_map_builders_under_sanitizers(tmp_path):
     cmd = ["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17",
            "-I" + src, "-I" + os.path.join(root, "include"), "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-o", exe,
            os.path.join(root, "tests", "host_asan.cpp")] + [os.path.join(src, f) for f in
-                                                            ("pattern.cpp", "patches.cpp", "gather.cpp", "shard.cpp", "amg_setup.cpp")] + ["-lpthread"]
+                                                            ("pattern.cpp", "patches.cpp", "gather.cpp", "gather10.cpp", "shard.cpp", "amg_setup.cpp")] + ["-lpthread"]
     subprocess.run(cmd, check=True, capture_output=True, timeout=600)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "ERROR" not in r.stderr and "runtime error" not in r.stderr
-    assert "patches=1 visits=1 pairs=1 gather=1/1" in r.stdout and "quad=1/1" in r.stdout and r.stdout.count("amg: ok=1") == 2
+    assert "patches=1 visits=1 pairs=1 gather=1/1" in r.stdout and "quad=1/1" in r.stdout and "gather10=1/1" in r.stdout and r.stdout.count("amg: ok=1") == 2
 
 
-@pytest.mark.parametrize("quadratic,brick", [(False, None), (False, (4, 2, 2)), (True, None)])
+@pytest.mark.parametrize("quadratic,brick", [(False, None), (False, (4, 2, 2)), (True, None), (True, (3, 4, 4))])
 def test_per_rank_assembly_maps_say_what_the_unsharded_maps_say(quadratic, brick):
-    """A rank of a sharded run builds the assembly maps of ITS block rows only (gather chunks for linear tets,
-    shared-state chunks for 10-node tets), cut from its first row -- so they are not slices of the unsharded maps,
+    """A rank of a sharded run builds the assembly maps of ITS block rows only (gather chunks for linear and for
+    10-node tets, shared-state chunks where those do not build), cut from its first row -- so they are not slices of the unsharded maps,
     but what they say about a row must be the same: for every row, the set of (row, column, element, local row
     node, local column node) contributions listed (mirror blocks expanded), compared through one hash per row.
     Also an independent restatement: the hash of a row from the element list alone.  Host only, no device."""
