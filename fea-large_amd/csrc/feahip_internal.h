@@ -320,7 +320,7 @@ struct HostGather10 {
 };
 void build_host_gather10(int N, int E, const int *conn, const HostPattern &hp, int row_lo, int row_hi, HostGather10 &out);
 int ensure_gather10(feahip_ctx *c);
-int launch_assemble_gather10(feahip_ctx *c, bool doF);
+int launch_assemble_gather10(feahip_ctx *c, bool doK, bool doF);
 
 struct HostPairs {
   std::vector<VisitDesc> desc;       // visit_off / nvisit = first pair / pairs of the chunk

@@ -319,9 +319,10 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
         if (c->have_visits) strat = FEAHIP_ASM_STAGED;
       }
     }
-    if (strat == FEAHIP_ASM_AUTO && c->npe == 10 && doK) {
-      // 10-node tetrahedra: gather chunks of up to 32 rows where the numbering keeps them compact (an element is
-      // evaluated ~3 times with a brick numbering, 8 times by the 3-row chunks of the shared-state kernel)
+    if (strat == FEAHIP_ASM_AUTO && c->npe == 10) {
+      // 10-node tetrahedra: gather chunks of up to 64 rows where the numbering keeps them compact (an element's
+      // records are expanded in ~3 chunks with a brick numbering; lexicographic ids: ~5, still ahead of the 3-row
+      // chunks of the shared-state kernel, which evaluate an element 8 times)
       { const int rc = ensure_gather10(c); if (rc) return rc; }
       if (c->have_gather && c->gather_evals_per_element <= 6.0) strat = FEAHIP_ASM_GATHER;
     }
@@ -346,11 +347,8 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
       c->err = "gather assembly of 10-node tetrahedra needs rows that fit the LDS tiles";
       return FEAHIP_EINVAL;
     }
-    if (!doK) strat = rowowner_ok ? FEAHIP_ASM_ROWOWNER : FEAHIP_ASM_ATOMIC;      // residual alone: visit kernel
-    else {
-      FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));
-      return launch_assemble_gather10(c, doF);
-    }
+    if (doK) FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));
+    return launch_assemble_gather10(c, doK, doF);
   }
   if (strat == FEAHIP_ASM_GATHER) {
     { const int rc = ensure_gather(c); if (rc) return rc; }

@@ -82,7 +82,7 @@ void k_state10(S10Args A)
   double sig[3][3], l1, m1;
   fd_constitutive(F, A.model, A.lambda, A.mu, sig, l1, m1);
   // counted once per mesh: by the rank that owns the element's first node
-  if (!(detJ > 0.0) && n0 >= A.row0 && n0 < A.row1) atomicAdd(A.bad, 1);
+  if (A.bad && !(detJ > 0.0) && n0 >= A.row0 && n0 < A.row1) atomicAdd(A.bad, 1);
   double st[T_HDR];
 #pragma unroll
   for (int i = 0; i < T_HDR; ++i) st[i] = 0.0;
@@ -182,7 +182,8 @@ __device__ __forceinline__ void t_visit(const unsigned char *sRb, const double *
   if (DOF) { fa[0] -= sx; fa[1] -= sy; fa[2] -= sz; }
 }
 
-template <bool DOF>
+// DOK = false: the residual alone -- expand and the visit lanes only, no blocks, no tile
+template <bool DOK, bool DOF>
 __global__ __launch_bounds__(FEA_Q_THREADS, 2)
 void k_assemble_gather10(G10Args A, int run_len)
 {
@@ -241,9 +242,9 @@ void k_assemble_gather10(G10Args A, int run_len)
     const uint32_t *cl = reinterpret_cast<const uint32_t *>(rec + A.lay.o_clist) + t;
 #pragma unroll
     for (int s = 0; s < FEA_Q_SLOTS; ++s) {
-      tp[s] = reinterpret_cast<const uint32_t *>(rec + A.lay.o_tpos)[s * FEA_Q_THREADS + t];
+      tp[s] = DOK ? reinterpret_cast<const uint32_t *>(rec + A.lay.o_tpos)[s * FEA_Q_THREADS + t] : 0xFFFFFFFFu;
 #pragma unroll
-      for (int k = 0; k < FEA_Q_REGW; ++k) cw[s][k] = 2 * k < cnt[s] ? cl[(size_t)(srow[s] + k) * FEA_Q_THREADS] : ZZ;
+      for (int k = 0; k < FEA_Q_REGW; ++k) cw[s][k] = (DOK && 2 * k < cnt[s]) ? cl[(size_t)(srow[s] + k) * FEA_Q_THREADS] : ZZ;
     }
 #pragma unroll
     for (int k = 0; k < FEA_Q_REGW; ++k)
@@ -311,8 +312,10 @@ void k_assemble_gather10(G10Args A, int run_len)
         for (int k = 0; k < FEA_Q_REGW; ++k) asm volatile("" : "+v"(cw[s][k]));
 #pragma unroll
       for (int k = 0; k < FEA_Q_REGW; ++k) asm volatile("" : "+v"(fw[k]));
+      if (DOK) {
 #pragma unroll
-      for (int s = 0; s < FEA_Q_SLOTS; ++s) t_slot(sRb, cw[s], cl + (size_t)srow[s] * FEA_Q_THREADS, cnt[s], acc[s]);
+        for (int s = 0; s < FEA_Q_SLOTS; ++s) t_slot(sRb, cw[s], cl + (size_t)srow[s] * FEA_Q_THREADS, cnt[s], acc[s]);
+      }
       if (vlane) {
 #pragma unroll
         for (int k = 0; k < FEA_Q_REGW; ++k)
@@ -344,7 +347,7 @@ void k_assemble_gather10(G10Args A, int run_len)
         if (DOF && c >= 6) A.f[(size_t)(r0 + row) * 3 + (c - 6)] = s;
       }
     }
-    for (int p = 0; p < npass; ++p) {
+    for (int p = 0; p < (DOK ? npass : 0); ++p) {
       const int rlo = (int)(((p < 4 ? prow_lo >> (8 * p) : prow_hi >> (8 * (p - 4)))) & 255u);
       const int rhi = (int)(((p + 1 < 4 ? prow_lo >> (8 * (p + 1)) : prow_hi >> (8 * (p - 3)))) & 255u);
       const int pb0 = sRows[rlo], pb1 = sRows[rhi];
@@ -399,6 +402,7 @@ void k_assemble_gather10(G10Args A, int run_len)
       }
       T_BARRIER();                                       // the tile has been read
     }
+    if (!DOK) T_BARRIER();                               // the partials have been read
     T_STAMP(6);
   }
 #ifdef FEAHIP_DEBUG
@@ -446,14 +450,14 @@ static int gather10_lds_bytes(const Gather10Layout &lay, int G)
   return G * 40 * 8 + FEA_Q_FLANES * 9 * 8 + (lay.max_elems + 1) * 6 * 8 + 208 * 2 + (lay.max_elems + 1) * T_REC * 8;
 }
 
-int launch_assemble_gather10(feahip_ctx *c, bool doF)
+int launch_assemble_gather10(feahip_ctx *c, bool doK, bool doF)
 {
   if (c->ngchunks <= 0) return FEAHIP_OK;
   {
     S10Args S;
     S.nloc = c->g10_nloc; S.G = c->G; S.model = c->model; S.row0 = c->row0; S.row1 = c->row1; S.lambda = c->lambda; S.mu = c->mu;
     S.tab = c->d_table; S.elist = c->d_g10_elist; S.conn = c->d_conn; S.X0 = c->d_X0; S.x = c->d_x;
-    S.state = c->d_g10_state; S.bad = c->d_flag + 1;
+    S.state = c->d_g10_state; S.bad = doK ? c->d_flag + 1 : nullptr;      // the counter is reset by stiffness assemblies only
     const long long items = (long long)c->g10_nloc * c->G;
     if (items > 0) hipLaunchKernelGGL(k_state10, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, c->stream, S);
   }
@@ -474,17 +478,17 @@ int launch_assemble_gather10(feahip_ctx *c, bool doF)
   const int nruns = (c->ngchunks + run_len - 1) / run_len;
   const dim3 grid((nruns + 7) & ~7), blk(FEA_Q_THREADS);
   const int lds = gather10_lds_bytes(A.lay, c->G);
+  const void *fn = !doK ? reinterpret_cast<const void *>(&k_assemble_gather10<false, true>)
+                   : doF ? reinterpret_cast<const void *>(&k_assemble_gather10<true, true>)
+                         : reinterpret_cast<const void *>(&k_assemble_gather10<true, false>);
   if (lds > 64 * 1024) {
-    static bool raised_t = false, raised_f = false;
-    bool &raised = doF ? raised_t : raised_f;
-    if (!raised) {
-      if (doF) FEA_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assemble_gather10<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      else     FEA_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_assemble_gather10<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      raised = true;
-    }
+    static bool raised[3] = {false, false, false};
+    bool &r = raised[!doK ? 2 : (doF ? 1 : 0)];
+    if (!r) { FEA_HIP_CHECK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); r = true; }
   }
-  if (doF) hipLaunchKernelGGL((k_assemble_gather10<true>), grid, blk, lds, c->stream, A, run_len);
-  else     hipLaunchKernelGGL((k_assemble_gather10<false>), grid, blk, lds, c->stream, A, run_len);
+  if (!doK)     hipLaunchKernelGGL((k_assemble_gather10<false, true>), grid, blk, lds, c->stream, A, run_len);
+  else if (doF) hipLaunchKernelGGL((k_assemble_gather10<true, true>), grid, blk, lds, c->stream, A, run_len);
+  else          hipLaunchKernelGGL((k_assemble_gather10<true, false>), grid, blk, lds, c->stream, A, run_len);
   FEA_HIP_CHECK(c, hipGetLastError());
 #ifdef FEAHIP_DEBUG
   if (A.stamps) {
