@@ -18,14 +18,15 @@ def rel(a, b):
     return np.abs(a - b).max() / (s if s > 0 else 1.0)
 
 
-@pytest.mark.parametrize("strategy", [feahip.ASM_AUTO, feahip.ASM_STAGED])
+@pytest.mark.parametrize("strategy,quadratic", [(feahip.ASM_AUTO, False), (feahip.ASM_STAGED, False), (feahip.ASM_AUTO, True)])
 @pytest.mark.parametrize("n", [2, 3])
-def test_sharded_assembly_is_the_unsharded_one(n, strategy):
+def test_sharded_assembly_is_the_unsharded_one(n, strategy, quadratic):
     """Every rank assembles the rows it owns from maps built for those rows alone.  Staged visits: the same bits as
-    the unsharded run.  Gather (what AUTO picks here): the chunks of a shard start at its first row, so a block the
-    unsharded run writes as the transpose of its mirror may be summed directly (or the other way round) -- equal
-    to rounding, and the residual (no mirrors) to the bit."""
-    deck = mesh.bar_deck(dims=(3, 40, 3))
+    the unsharded run.  Gather (what AUTO picks here, for linear and for 10-node tetrahedra): the chunks of a shard
+    start at its first row, so a block the unsharded run writes as the transpose of its mirror may be summed directly
+    (or the other way round) -- equal to rounding; the residual of the 4-node kernel (no mirrors) to the bit, that of
+    the 10-node kernel (a row's visits are summed in slices whose length depends on the chunk) to rounding."""
+    deck = mesh.bar_deck(dims=(3, 20, 3), quadratic=True, brick=(3, 4, 4)) if quadratic else mesh.bar_deck(dims=(3, 40, 3))
     x = mesh.deformed_state(deck.nodes)
     one = feahip.FeaSolver(deck)
     one.set_nodes(x)
@@ -38,7 +39,7 @@ def test_sharded_assembly_is_the_unsharded_one(n, strategy):
     g.each("set_assembly", strategy)
     g.each("create_stiffness_and_residual")
     seen = np.zeros(len(deck.nodes), dtype=int)
-    kscale = np.abs(val).max()
+    kscale, fscale = np.abs(val).max(), np.abs(f).max()
     for (a, b), r in zip(g.rows, g.ranks):
         seen[a:b] += 1
         _, _, v = r.matrix_yale()
@@ -49,7 +50,12 @@ def test_sharded_assembly_is_the_unsharded_one(n, strategy):
             assert r.assembly_in_use() == feahip.ASM_GATHER
             assert np.abs(v[lo:hi] - val[lo:hi]).max() < 4e-16 * kscale
         assert np.all(v[:lo] == 0) and np.all(v[hi:] == 0)        # nothing else written
-        assert np.array_equal(r.forces()[3 * a:3 * b], f[3 * a:3 * b])
+        if quadratic:
+            assert np.abs(r.forces()[3 * a:3 * b] - f[3 * a:3 * b]).max() < 4e-16 * fscale
+            r.create_residual_forces()                            # the residual alone: same kernel without the blocks
+            assert np.abs(r.forces()[3 * a:3 * b] - f[3 * a:3 * b]).max() < 4e-16 * fscale
+        else:
+            assert np.array_equal(r.forces()[3 * a:3 * b], f[3 * a:3 * b])
     assert np.all(seen == 1)
     g.close(); one.close()
 
