@@ -28,7 +28,8 @@
 
 #define T_REC 62                      // doubles per element record (31 pieces)
 #define T_HDR 18                      // doubles per state record (Ji 9, S 6, vl, vm, pad)
-#define T_GMAX 32                     // Gauss points (the whole table sits in LDS)
+#define T_GMAX 32                     // Gauss points of a rule at most
+#define T_GLDS 8                      // rules up to this many points keep their shape-gradient table in LDS
 
 struct S10Args {
   int nloc, G, model, row0, row1;
@@ -191,7 +192,9 @@ __device__ __forceinline__ void t_visit(const unsigned char *sRb, const double *
 }
 
 // DOK = false: the residual alone -- expand and the visit lanes only, no blocks, no tile
-template <bool DOK, bool DOF>
+// TLDS: the shape-gradient table in LDS (rules of up to T_GLDS points); the 27-point rule reads it through the cache -- 8.6 KB
+// more LDS would cost the second workgroup of a CU
+template <bool DOK, bool DOF, bool TLDS>
 __global__ __launch_bounds__(FEA_Q_THREADS, 2)
 void k_assemble_gather10(G10Args A, int run_len)
 {
@@ -199,8 +202,8 @@ void k_assemble_gather10(G10Args A, int run_len)
   const int t = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int mxe = A.lay.max_elems, G = A.G;
-  double *sTd = reinterpret_cast<double *>(smem);                // [G][10][4]: dN/dxi of node k at Gauss point g, pad
-  double *sFp = sTd + G * 40;                                    // [FLANES][9] diagonal block (6) + residual (3) partials
+  double *sTd = reinterpret_cast<double *>(smem);                // [G][10][4]: dN/dxi of node k at Gauss point g, pad (TLDS)
+  double *sFp = sTd + (TLDS ? G * 40 : 0);                       // [FLANES][9] diagonal block (6) + residual (3) partials
   double *sS = sFp + FEA_Q_FLANES * 9;                           // [mxe + 1][6] volume-weighted stress 00 01 02 11 12 22
   uint16_t *sRows = reinterpret_cast<uint16_t *>(sS + (mxe + 1) * 6);        // [208]
   double *sR = reinterpret_cast<double *>(sRows + 208);          // [mxe + 1][62]; record mxe stays all-zero
@@ -215,7 +218,7 @@ void k_assemble_gather10(G10Args A, int run_len)
 #ifdef FEAHIP_DEBUG
   unsigned long long qa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, qt = __builtin_amdgcn_s_memtime();
 #endif
-  for (int i = t; i < G * 40; i += FEA_Q_THREADS) {
+  for (int i = t; i < (TLDS ? G * 40 : 0); i += FEA_Q_THREADS) {
     const int g = i / 40, k = (i % 40) >> 2, c = i & 3;
     sTd[i] = c < 3 ? A.tab->dN[g][c][k] : 0.0;
   }
@@ -280,9 +283,13 @@ void k_assemble_gather10(G10Args A, int run_len)
         for (int kk = 0; kk < 5; ++kk) {
           const int k = xp + kk * parts;
           if (k >= 10) break;
-          const double *td = sTd + (g * 10 + k) * 4;
-          const double2 d01 = *reinterpret_cast<const double2 *>(td);
-          const double d2 = td[2];
+          double2 d01; double d2;
+          if (TLDS) {
+            const double *td = sTd + (g * 10 + k) * 4;
+            d01 = *reinterpret_cast<const double2 *>(td); d2 = td[2];
+          } else {
+            d01 = make_double2(A.tab->dN[g][0][k], A.tab->dN[g][1][k]); d2 = A.tab->dN[g][2][k];
+          }
           // g_i = sum_m Ji[i][m] dN[m];  S = (h4.y h5.x h5.y; . h6.x h6.y; . . h7.x)
           const double gx = h[0].x * d01.x + h[0].y * d01.y + h[1].x * d2;
           const double gy = h[1].y * d01.x + h[2].x * d01.y + h[2].y * d2;
@@ -455,7 +462,7 @@ int ensure_gather10(feahip_ctx *c)
 
 static int gather10_lds_bytes(const Gather10Layout &lay, int G)
 {
-  return G * 40 * 8 + FEA_Q_FLANES * 9 * 8 + (lay.max_elems + 1) * 6 * 8 + 208 * 2 + (lay.max_elems + 1) * T_REC * 8;
+  return (G <= T_GLDS ? G * 40 * 8 : 0) + FEA_Q_FLANES * 9 * 8 + (lay.max_elems + 1) * 6 * 8 + 208 * 2 + (lay.max_elems + 1) * T_REC * 8;
 }
 
 int launch_assemble_gather10(feahip_ctx *c, bool doK, bool doF)
@@ -485,17 +492,25 @@ int launch_assemble_gather10(feahip_ctx *c, bool doK, bool doF)
   const int nruns = (c->ngchunks + run_len - 1) / run_len;
   const dim3 grid((nruns + 7) & ~7), blk(FEA_Q_THREADS);
   const int lds = gather10_lds_bytes(A.lay, c->G);
-  const void *fn = !doK ? reinterpret_cast<const void *>(&k_assemble_gather10<false, true>)
-                   : doF ? reinterpret_cast<const void *>(&k_assemble_gather10<true, true>)
-                         : reinterpret_cast<const void *>(&k_assemble_gather10<true, false>);
+  const bool tl = c->G <= T_GLDS;
+  const int variant = (!doK ? 2 : (doF ? 1 : 0)) * 2 + (tl ? 1 : 0);
+#define G10_KERNEL(K_, F_, T_) k_assemble_gather10<K_, F_, T_>
+  const void *fns[6] = {reinterpret_cast<const void *>(&G10_KERNEL(true, false, false)), reinterpret_cast<const void *>(&G10_KERNEL(true, false, true)),
+                        reinterpret_cast<const void *>(&G10_KERNEL(true, true, false)), reinterpret_cast<const void *>(&G10_KERNEL(true, true, true)),
+                        reinterpret_cast<const void *>(&G10_KERNEL(false, true, false)), reinterpret_cast<const void *>(&G10_KERNEL(false, true, true))};
   if (lds > 64 * 1024) {
-    static bool raised[3] = {false, false, false};
-    bool &r = raised[!doK ? 2 : (doF ? 1 : 0)];
-    if (!r) { FEA_HIP_CHECK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); r = true; }
+    static bool raised[6] = {false, false, false, false, false, false};
+    if (!raised[variant]) { FEA_HIP_CHECK(c, hipFuncSetAttribute(fns[variant], hipFuncAttributeMaxDynamicSharedMemorySize, lds)); raised[variant] = true; }
   }
-  if (!doK)     hipLaunchKernelGGL((k_assemble_gather10<false, true>), grid, blk, lds, c->stream, A, run_len);
-  else if (doF) hipLaunchKernelGGL((k_assemble_gather10<true, true>), grid, blk, lds, c->stream, A, run_len);
-  else          hipLaunchKernelGGL((k_assemble_gather10<true, false>), grid, blk, lds, c->stream, A, run_len);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL((G10_KERNEL(true, false, false)), grid, blk, lds, c->stream, A, run_len); break;
+    case 1: hipLaunchKernelGGL((G10_KERNEL(true, false, true)), grid, blk, lds, c->stream, A, run_len); break;
+    case 2: hipLaunchKernelGGL((G10_KERNEL(true, true, false)), grid, blk, lds, c->stream, A, run_len); break;
+    case 3: hipLaunchKernelGGL((G10_KERNEL(true, true, true)), grid, blk, lds, c->stream, A, run_len); break;
+    case 4: hipLaunchKernelGGL((G10_KERNEL(false, true, false)), grid, blk, lds, c->stream, A, run_len); break;
+    default: hipLaunchKernelGGL((G10_KERNEL(false, true, true)), grid, blk, lds, c->stream, A, run_len); break;
+  }
+#undef G10_KERNEL
   FEA_HIP_CHECK(c, hipGetLastError());
 #ifdef FEAHIP_DEBUG
   if (A.stamps) {
