@@ -68,9 +68,12 @@ enum {
                               of block rows; every element touching them is
                               evaluated once into an LDS record, one thread
                               per off-diagonal block then sums that block's
-                              element contributions in registers.  No
-                              atomics anywhere, fixed summation order:
-                              bitwise reproducible                           */
+                              element contributions in registers.  10-node
+                              tets: the same with the Gauss points as an
+                              outer loop over per-element state records a
+                              first kernel wrote, up to five blocks per
+                              thread.  No atomics anywhere, fixed summation
+                              order: bitwise reproducible                     */
 };
 
 /* ---- lifetime ----------------------------------------------------------- */
