@@ -180,9 +180,9 @@ def main():
             dist.barrier()
 
     t_setup = time.perf_counter()
-    # 'brick': 4x2x2 nodes for the corner-node meshes, 3x4x4 nodes of the half-spacing grid for 10-node tetrahedra (48
-    # rows: one gather chunk of kernels_gather10.hip)
-    brick = (None if args.numbering == "lex" else ((3, 4, 4) if args.quadratic else (4, 2, 2)) if args.numbering == "brick"
+    # 'brick': 4x2x2 nodes for linear tetrahedra, 3x4x4 nodes of the half-spacing grid for 10-node tetrahedra (48 rows: one
+    # gather chunk of kernels_gather10.hip), 4x4x4 nodes for 8-node bricks
+    brick = (None if args.numbering == "lex" else ((3, 4, 4) if args.quadratic else (4, 4, 4) if args.hex else (4, 2, 2)) if args.numbering == "brick"
              else tuple(int(v) for v in args.numbering.split(",")))
     deck = mesh.bar_deck(n=args.n, quadratic=args.quadratic, hexa=args.hex, recipe="clamped", model=model, brick=brick,
                          solver_type=feahip.PCG_ILU, solver_tolerance=1e-14, solver_max_iter=20000)
@@ -201,7 +201,7 @@ def main():
     t_setup = time.perf_counter() - t_setup
     dev_bytes = free0 - torch.cuda.mem_get_info(local)[0]
     in_use = solver.assembly_in_use()
-    kernel = {feahip.ASM_GATHER: "k_assemble_gather10" if args.quadratic else "k_assemble_gather", feahip.ASM_STAGED: "k_assemble_visit", feahip.ASM_PIPELINED: "k_assemble_run",
+    kernel = {feahip.ASM_GATHER: "k_assemble_gather10" if (args.quadratic or args.hex) else "k_assemble_gather", feahip.ASM_STAGED: "k_assemble_visit", feahip.ASM_PIPELINED: "k_assemble_run",
               feahip.ASM_SHARED: "k_assemble_quad", feahip.ASM_PATCH: "k_assemble_patch", feahip.ASM_PAIRED: "k_assemble_pair",
               feahip.ASM_ATOMIC: "k_assemble_atomic"}.get(in_use, "k_assemble_rowowner")
 

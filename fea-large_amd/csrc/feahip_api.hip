@@ -216,8 +216,8 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
     // the strategy allows (gather)
     c->h_conn.assign(elements, elements + (size_t)n_elems * npe);
   } else if ((rc = ensure_generic_maps(c))) return rc;
-  if (npe == 10) c->h_conn.assign(elements, elements + (size_t)n_elems * npe);      // shared-state maps: built per shard on first use
-  if (!lin1 && npe != 10) { delete c->h_pat; c->h_pat = nullptr; }                   // nothing is built later for these meshes
+  if (npe == 10 || npe == 8) c->h_conn.assign(elements, elements + (size_t)n_elems * npe);      // gather / shared-state maps: built per shard on first use
+  if (!lin1 && npe != 10 && npe != 8) { delete c->h_pat; c->h_pat = nullptr; }                   // nothing is built later for these meshes
   if ((rc = dev_zeros(c, &c->d_f, (size_t)c->ndof))) return rc;
   if ((rc = dev_zeros(c, &c->d_u, (size_t)c->ndof))) return rc;
   if ((rc = dev_zeros(c, &c->d_r, (size_t)c->ndof))) return rc;

@@ -314,11 +314,12 @@ struct HostGather10 {
   std::vector<unsigned char> blob;
   std::vector<int> first_row;
   std::vector<int> elist;            // the rank's elements (touching its rows), ascending: order of the state records
+  int npe = 10;
   long long total_evals = 0, distinct_elems = 0;
   int nchunks = 0;
   bool ok = false;
 };
-void build_host_gather10(int N, int E, const int *conn, const HostPattern &hp, int row_lo, int row_hi, HostGather10 &out);
+void build_host_gather10(int N, int E, int npe, const int *conn, const HostPattern &hp, int row_lo, int row_hi, HostGather10 &out);
 int ensure_gather10(feahip_ctx *c);
 int launch_assemble_gather10(feahip_ctx *c, bool doK, bool doF);
 

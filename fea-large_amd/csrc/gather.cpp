@@ -498,11 +498,12 @@ void gather_row_digest(const HostGather &hg, const HostPattern &hp, unsigned lon
 void gather10_row_digest(const HostGather10 &hg, const HostPattern &hp, const int *conn, unsigned long long *rowhash,
                          unsigned long long (*hash)(int, int, const int *, int, int));     // gather10.cpp
 namespace {
+int hash_npe = 10;           // nodes per element of the mesh being digested (host-only, single-threaded)
 unsigned long long contribution_hash10(int a, int b, const int *g, int la, int lb)
 {
   unsigned long long h = 0x1234567ull;
   h = mix(h, (unsigned long long)a); h = mix(h, (unsigned long long)b);
-  for (int k = 0; k < 10; ++k) h = mix(h, (unsigned long long)g[k]);
+  for (int k = 0; k < hash_npe; ++k) h = mix(h, (unsigned long long)g[k]);
   return mix(h, (unsigned long long)(la * 16 + lb));
 }
 }  // namespace
@@ -546,9 +547,10 @@ extern "C" int feahip_host_assembly_digest(int n_nodes, int n_elems, int npe, co
     // is not evaluated by too many chunks, the shared-state maps otherwise.  Both list every off-diagonal
     // contribution (the gather maps' mirror blocks are expanded); neither digest covers the diagonal blocks.
     bool done = false;
-    if (npe == 10) {
+    if (npe == 10 || npe == 8) {
       HostGather10 hg;
-      build_host_gather10(n_nodes, n_elems, elements, hp, row0, row1, hg);
+      hash_npe = npe;
+      build_host_gather10(n_nodes, n_elems, npe, elements, hp, row0, row1, hg);
       if (hg.ok && (double)hg.total_evals <= 6.0 * (double)hg.distinct_elems) {
         gather10_row_digest(hg, hp, elements, rowhash, contribution_hash10);
         done = true;

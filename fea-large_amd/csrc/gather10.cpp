@@ -1,5 +1,6 @@
 // gather10.cpp -- one-time host construction of the maps of the GATHER assembly
-// of 10-node tetrahedra (kernels_gather10.hip).
+// of elements with several Gauss points: 10-node tetrahedra, 8-node bricks
+// (kernels_gather10.hip).
 //
 // The reference integrates a 30x30 element matrix Gauss point by Gauss point
 // and scatters it (fea_solver.c:887-1068, sp_matrix_element_add :966,1055).
@@ -44,17 +45,18 @@ inline int up10(int v, int m) { return (v + m - 1) / m * m; }
 #define Q_MAX_TASKS (FEA_Q_SLOTS * FEA_Q_THREADS)
 #define Q_FENT 8                        // visits per residual lane at most (4 words)
 
-void build_host_gather10(int N, int E, const int *conn, const HostPattern &hp, int row_lo, int row_hi, HostGather10 &out)
+void build_host_gather10(int N, int E, int npe, const int *conn, const HostPattern &hp, int row_lo, int row_hi, HostGather10 &out)
 {
   (void)E; (void)N;
-  out.ok = false; out.nchunks = 0; out.blob.clear(); out.first_row.clear();
+  out.ok = false; out.nchunks = 0; out.blob.clear(); out.first_row.clear(); out.npe = npe;
+  if (npe < 2 || npe > 15) return;                     // 4-bit local node ids
   if (row_lo < 0 || row_hi > N || row_lo >= row_hi) return;
   // limits of one chunk: two workgroups' records (496 bytes per element) in one CU's LDS
   int max_rows = FEA_Q_MAX_ROWS, max_elems = 127, alpha = 8;
   if (const char *e = getenv("FEAHIP_GATHER10_ROWS")) max_rows = std::max(1, std::min(FEA_Q_MAX_ROWS, atoi(e)));
   if (const char *e = getenv("FEAHIP_GATHER10_ELEMS")) max_elems = std::max(4, std::min(FEA_Q_MAX_ELEMS, atoi(e)));
   if (const char *e = getenv("FEAHIP_GATHER10_ALPHA")) alpha = std::max(0, atoi(e));
-  const int tile_blocks = (max_elems * 496) / 72 - 1;
+  const int tile_blocks = (max_elems * (3 * npe + 1) * 16) / 72 - 1;   // the K tile takes the records' place
   const int nrows_all = row_hi - row_lo;
 
   // ---- pass A: chunk boundaries by the shortest-path recurrence of gather.cpp (cost = element evaluations)
@@ -69,8 +71,8 @@ void build_host_gather10(int N, int E, const int *conn, const HostPattern &hp, i
         for (int q = hp.incptr[r]; q < hp.incptr[r + 1]; ++q) {
           const int e = (int)(hp.inc_rows[q] & 0x0FFFFFFFu), la = (int)(hp.inc_rows[q] >> 28);
           bool fresh = true;
-          for (int k = 0; k < 10; ++k) {
-            const int g = conn[(size_t)e * 10 + k];
+          for (int k = 0; k < npe; ++k) {
+            const int g = conn[(size_t)e * npe + k];
             if (k != la && g >= r0 && g < r) fresh = false;
           }
           if (fresh) ++nel;
@@ -171,9 +173,9 @@ void build_host_gather10(int N, int E, const int *conn, const HostPattern &hp, i
         for (int q = hp.incptr[a]; q < hp.incptr[a + 1]; ++q) {
           const int e = (int)(hp.inc_rows[q] & 0x0FFFFFFFu), la = (int)(hp.inc_rows[q] >> 28);
           const int le = lelem(e);
-          for (int lb = 0; lb < 10; ++lb) {
+          for (int lb = 0; lb < npe; ++lb) {
             if (lb == la) continue;
-            const int b = conn[(size_t)e * 10 + lb];
+            const int b = conn[(size_t)e * npe + lb];
             if (b == a) continue;                 // repeated node: no off-diagonal block
             const int pos = hp.rowptr[a] + (int)(std::lower_bound(cb, ce, b) - cb) - b0;
             if (tid_of[pos] < 0) continue;        // served by the mirror block's thread
@@ -311,8 +313,8 @@ void build_host_gather10(int N, int E, const int *conn, const HostPattern &hp, i
       for (int q = hp.incptr[a]; q < hp.incptr[a + 1]; ++q) {
         const int e = (int)(hp.inc_rows[q] & 0x0FFFFFFFu), la = (int)(hp.inc_rows[q] >> 28);
         bool first = true;
-        for (int k = 0; k < 10; ++k) {
-          const int g = conn[(size_t)e * 10 + k];
+        for (int k = 0; k < npe; ++k) {
+          const int g = conn[(size_t)e * npe + k];
           if (k != la && g >= row_lo && g < a) first = false;
         }
         d += first;
@@ -349,8 +351,8 @@ void gather10_row_digest(const HostGather10 &hg, const HostPattern &hp, const in
           const uint16_t w = cl[(((size_t)row0 + k / 2) * FEA_Q_THREADS + t) * 2 + (k & 1)];
           const int le = w & 127, la = (w >> 7) & 15, lb = (w >> 11) & 15;
           if (le == lay.max_elems) continue;
-          int g[10];
-          for (int j = 0; j < 10; ++j) g[j] = conn[(size_t)hg.elist[elems[le]] * 10 + j];
+          int g[16];
+          for (int j = 0; j < hg.npe; ++j) g[j] = conn[(size_t)hg.elist[elems[le]] * hg.npe + j];
           rowhash[a] += hash(a, b, g, la, lb);
           if (mpos != 0xFFFF) rowhash[b] += hash(b, a, g, lb, la);
         }

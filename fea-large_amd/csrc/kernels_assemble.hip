@@ -319,8 +319,8 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
         if (c->have_visits) strat = FEAHIP_ASM_STAGED;
       }
     }
-    if (strat == FEAHIP_ASM_AUTO && c->npe == 10) {
-      // 10-node tetrahedra: gather chunks of up to 64 rows where the numbering keeps them compact (an element's
+    if (strat == FEAHIP_ASM_AUTO && (c->npe == 10 || c->npe == 8)) {
+      // 10-node tetrahedra, 8-node bricks: gather chunks of up to 64 rows where the numbering keeps them compact (an element's
       // records are expanded in ~3 chunks with a brick numbering; lexicographic ids: ~5, still ahead of the 3-row
       // chunks of the shared-state kernel, which evaluate an element 8 times)
       { const int rc = ensure_gather10(c); if (rc) return rc; }
@@ -341,10 +341,10 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
     FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));
     return launch_assemble_quad(c, doF);
   }
-  if (strat == FEAHIP_ASM_GATHER && c->npe == 10) {
+  if (strat == FEAHIP_ASM_GATHER && (c->npe == 10 || c->npe == 8)) {
     { const int rc = ensure_gather10(c); if (rc) return rc; }
     if (!c->have_gather) {
-      c->err = "gather assembly of 10-node tetrahedra needs rows that fit the LDS tiles";
+      c->err = "gather assembly of 10-node tetrahedra / 8-node bricks needs rows that fit the LDS tiles";
       return FEAHIP_EINVAL;
     }
     if (doK) FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));

@@ -26,7 +26,8 @@
 #include <cstdlib>
 #include <vector>
 
-#define T_REC 62                      // doubles per element record (31 pieces)
+// doubles per element record: 3 NPE + 1 pieces of 16 bytes (31 for ten nodes, 25 for eight)
+#define T_RECD(NPE) (6 * (NPE) + 2)
 #define T_HDR 18                      // doubles per state record (Ji 9, S 6, vl, vm, pad)
 #define T_GMAX 32                     // Gauss points of a rule at most
 #define T_GLDS 8                      // rules up to this many points keep their shape-gradient table in LDS
@@ -43,22 +44,23 @@ struct S10Args {
 
 // thread <-> element, its Gauss points one after the other with the twenty coordinate triples held in registers (one
 // thread per (element, Gauss point) gathered them G times: 0.18 ms of the 1.11 ms assembly at G = 5)
+template <int NPE>
 __global__ __launch_bounds__(256)
 void k_state10(S10Args A)
 {
-  __shared__ double sTd[T_GMAX * 30];
+  __shared__ double sTd[T_GMAX * 3 * NPE];
   __shared__ double sTw[T_GMAX];
   for (int i = threadIdx.x; i < A.G; i += 256) sTw[i] = A.tab->w[i];
-  for (int i = threadIdx.x; i < A.G * 30; i += 256) sTd[i] = A.tab->dN[i / 30][(i / 10) % 3][i % 10];
+  for (int i = threadIdx.x; i < A.G * 3 * NPE; i += 256) sTd[i] = A.tab->dN[i / (3 * NPE)][(i / NPE) % 3][i % NPE];
   __syncthreads();
   const int le = blockIdx.x * 256 + threadIdx.x;
   if (le >= A.nloc) return;
   const int e = A.elist[le];
-  const int *cn = A.conn + (size_t)e * 10;
-  double xc[10][3], Xc[10][3];
+  const int *cn = A.conn + (size_t)e * NPE;
+  double xc[NPE][3], Xc[NPE][3];
   int n0 = 0;
 #pragma unroll
-  for (int k = 0; k < 10; ++k) {
+  for (int k = 0; k < NPE; ++k) {
     const size_t n = (size_t)cn[k];
     if (k == 0) n0 = (int)n;
     const double2 a0 = *reinterpret_cast<const double2 *>(A.x + n * 4), c0 = *reinterpret_cast<const double2 *>(A.X0 + n * 4);
@@ -69,12 +71,12 @@ void k_state10(S10Args A)
   int nbad = 0;
   for (int g = 0; g < A.G; ++g) {
     double J[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, M[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    const double *td = sTd + g * 30;
+    const double *td = sTd + g * 3 * NPE;
 #pragma unroll
-    for (int k = 0; k < 10; ++k)
+    for (int k = 0; k < NPE; ++k)
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        const double dn_ = td[i * 10 + k];
+        const double dn_ = td[i * NPE + k];
 #pragma unroll
         for (int j = 0; j < 3; ++j) { J[i][j] = fma(dn_, xc[k][j], J[i][j]); M[i][j] = fma(dn_, Xc[k][j], M[i][j]); }
       }
@@ -129,16 +131,17 @@ struct G10Args {
                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
 
 // one contribution (element le, local row node la, local column node lb) to a block
+template <int NPE>
 __device__ __forceinline__ void t_entry(const unsigned char *sRb, uint32_t w, double (&acc)[9])
 {
   const uint32_t le = w & 127u, la = (w >> 7) & 15u, lb = (w >> 11) & 15u;
-  const unsigned char *base = sRb + le * (T_REC * 8u);
+  const unsigned char *base = sRb + le * (T_RECD(NPE) * 8u);
   const double2 Pa = *reinterpret_cast<const double2 *>(base + la * 16u);
-  const double Zax = *reinterpret_cast<const double *>(base + 320u + la * 16u);
+  const double Zax = *reinterpret_cast<const double *>(base + 32u * NPE + la * 16u);
   const double2 Pb = *reinterpret_cast<const double2 *>(base + lb * 16u);
-  const double2 Qb = *reinterpret_cast<const double2 *>(base + 160u + lb * 16u);
-  const double2 Zb = *reinterpret_cast<const double2 *>(base + 320u + lb * 16u);
-  const double2 VV = *reinterpret_cast<const double2 *>(base + 480u);
+  const double2 Qb = *reinterpret_cast<const double2 *>(base + 16u * NPE + lb * 16u);
+  const double2 Zb = *reinterpret_cast<const double2 *>(base + 32u * NPE + lb * 16u);
+  const double2 VV = *reinterpret_cast<const double2 *>(base + 48u * NPE);
   const double ga[3] = {Pa.x, Pa.y, Zax}, gb[3] = {Pb.x, Pb.y, Zb.x};
   const double d = ga[0] * Qb.x + ga[1] * Qb.y + ga[2] * Zb.y;
   const double A_[3] = {VV.x * ga[0], VV.x * ga[1], VV.x * ga[2]};
@@ -152,17 +155,18 @@ __device__ __forceinline__ void t_entry(const unsigned char *sRb, uint32_t w, do
 }
 
 // the contributions of one block slot: `cnt` entries (wave-uniform), the first 2*FEA_Q_REGW from registers
+template <int NPE>
 __device__ __forceinline__ void t_slot(const unsigned char *sRb, const uint32_t (&cw)[FEA_Q_REGW], const uint32_t *more, int cnt, double (&acc)[9])
 {
 #pragma unroll
   for (int k = 0; k < FEA_Q_REGW; ++k) {
-    if (2 * k < cnt) t_entry(sRb, cw[k] & 0xFFFFu, acc);
-    if (2 * k + 1 < cnt) t_entry(sRb, cw[k] >> 16, acc);
+    if (2 * k < cnt) t_entry<NPE>(sRb, cw[k] & 0xFFFFu, acc);
+    if (2 * k + 1 < cnt) t_entry<NPE>(sRb, cw[k] >> 16, acc);
   }
   for (int k = FEA_Q_REGW; 2 * k < cnt; ++k) {          // lists longer than the registers hold: the rest from memory
     const uint32_t w = more[(size_t)k * FEA_Q_THREADS];
-    t_entry(sRb, w & 0xFFFFu, acc);
-    if (2 * k + 1 < cnt) t_entry(sRb, w >> 16, acc);
+    t_entry<NPE>(sRb, w & 0xFFFFu, acc);
+    if (2 * k + 1 < cnt) t_entry<NPE>(sRb, w >> 16, acc);
   }
 }
 
@@ -170,14 +174,14 @@ __device__ __forceinline__ void t_slot(const unsigned char *sRb, const uint32_t 
 // 22) and the residual f_a -= S g_a.  S g_a is formed from S here, not as t_a - vm g_a: that difference carries the
 // rounding of vm g_a (the stiffness scale) into a quantity of the stress scale, which showed as a convergence floor
 // of <u, R> ~ 1e-16 where the other kernels reach 1e-26 on the reference's analytical decks.
-template <bool DOF>
+template <int NPE, bool DOF>
 __device__ __forceinline__ void t_visit(const unsigned char *sRb, const double *sS, uint32_t w, double (&kd)[6], double (&fa)[3])
 {
   const uint32_t le = w & 127u, la = (w >> 7) & 15u;
-  const unsigned char *base = sRb + le * (T_REC * 8u);
+  const unsigned char *base = sRb + le * (T_RECD(NPE) * 8u);
   const double2 Pa = *reinterpret_cast<const double2 *>(base + la * 16u);
-  const double gz = *reinterpret_cast<const double *>(base + 320u + la * 16u);
-  const double2 VV = *reinterpret_cast<const double2 *>(base + 480u);
+  const double gz = *reinterpret_cast<const double *>(base + 32u * NPE + la * 16u);
+  const double2 VV = *reinterpret_cast<const double2 *>(base + 48u * NPE);
   const double2 s0 = *reinterpret_cast<const double2 *>(sS + le * 6), s1 = *reinterpret_cast<const double2 *>(sS + le * 6 + 2),
                 s2 = *reinterpret_cast<const double2 *>(sS + le * 6 + 4);      // 00 01 | 02 11 | 12 22
   const double sx = s0.x * Pa.x + s0.y * Pa.y + s1.x * gz;
@@ -194,16 +198,17 @@ __device__ __forceinline__ void t_visit(const unsigned char *sRb, const double *
 // DOK = false: the residual alone -- expand and the visit lanes only, no blocks, no tile
 // TLDS: the shape-gradient table in LDS (rules of up to T_GLDS points); the 27-point rule reads it through the cache -- 8.6 KB
 // more LDS would cost the second workgroup of a CU
-template <bool DOK, bool DOF, bool TLDS>
+template <int NPE, bool DOK, bool DOF, bool TLDS>
 __global__ __launch_bounds__(FEA_Q_THREADS, 2)
 void k_assemble_gather10(G10Args A, int run_len)
 {
+  constexpr int T_REC = T_RECD(NPE);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int mxe = A.lay.max_elems, G = A.G;
   double *sTd = reinterpret_cast<double *>(smem);                // [G][10][4]: dN/dxi of node k at Gauss point g, pad (TLDS)
-  double *sFp = sTd + (TLDS ? G * 40 : 0);                       // [FLANES][9] diagonal block (6) + residual (3) partials
+  double *sFp = sTd + (TLDS ? G * NPE * 4 : 0);                       // [FLANES][9] diagonal block (6) + residual (3) partials
   double *sS = sFp + FEA_Q_FLANES * 9;                           // [mxe + 1][6] volume-weighted stress 00 01 02 11 12 22
   uint16_t *sRows = reinterpret_cast<uint16_t *>(sS + (mxe + 1) * 6);        // [208]
   double *sR = reinterpret_cast<double *>(sRows + 208);          // [mxe + 1][62]; record mxe stays all-zero
@@ -218,8 +223,8 @@ void k_assemble_gather10(G10Args A, int run_len)
 #ifdef FEAHIP_DEBUG
   unsigned long long qa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, qt = __builtin_amdgcn_s_memtime();
 #endif
-  for (int i = t; i < (TLDS ? G * 40 : 0); i += FEA_Q_THREADS) {
-    const int g = i / 40, k = (i % 40) >> 2, c = i & 3;
+  for (int i = t; i < (TLDS ? G * NPE * 4 : 0); i += FEA_Q_THREADS) {
+    const int g = i / (NPE * 4), k = (i % (NPE * 4)) >> 2, c = i & 3;
     sTd[i] = c < 3 ? A.tab->dN[g][c][k] : 0.0;
   }
   if (t < T_REC) sR[mxe * T_REC + t] = 0.0;
@@ -282,10 +287,10 @@ void k_assemble_gather10(G10Args A, int run_len)
 #pragma unroll
         for (int kk = 0; kk < 5; ++kk) {
           const int k = xp + kk * parts;
-          if (k >= 10) break;
+          if (k >= NPE) break;
           double2 d01; double d2;
           if (TLDS) {
-            const double *td = sTd + (g * 10 + k) * 4;
+            const double *td = sTd + (g * NPE + k) * 4;
             d01 = *reinterpret_cast<const double2 *>(td); d2 = td[2];
           } else {
             d01 = make_double2(A.tab->dN[g][0][k], A.tab->dN[g][1][k]); d2 = A.tab->dN[g][2][k];
@@ -299,11 +304,11 @@ void k_assemble_gather10(G10Args A, int run_len)
           const double sz = h[5].y * gx + h[6].y * gy + h[7].x * gz;
           const double tx = __dadd_rn(__dmul_rn(vm, gx), sx), ty = __dadd_rn(__dmul_rn(vm, gy), sy), tz = __dadd_rn(__dmul_rn(vm, gz), sz);
           *reinterpret_cast<double2 *>(r + 2 * k) = make_double2(gx, gy);
-          *reinterpret_cast<double2 *>(r + 20 + 2 * k) = make_double2(tx, ty);
-          *reinterpret_cast<double2 *>(r + 40 + 2 * k) = make_double2(gz, tz);
+          *reinterpret_cast<double2 *>(r + 2 * NPE + 2 * k) = make_double2(tx, ty);
+          *reinterpret_cast<double2 *>(r + 4 * NPE + 2 * k) = make_double2(gz, tz);
         }
         if (xp == 0) {
-          *reinterpret_cast<double2 *>(r + 60) = make_double2(vl, vm);
+          *reinterpret_cast<double2 *>(r + 6 * NPE) = make_double2(vl, vm);
           double *ss = sS + xe * 6;
           *reinterpret_cast<double2 *>(ss) = make_double2(h[4].y, h[5].x);
           *reinterpret_cast<double2 *>(ss + 2) = make_double2(h[5].y, h[6].x);
@@ -329,12 +334,12 @@ void k_assemble_gather10(G10Args A, int run_len)
       for (int k = 0; k < FEA_Q_REGW; ++k) asm volatile("" : "+v"(fw[k]));
       if (DOK) {
 #pragma unroll
-        for (int s = 0; s < FEA_Q_SLOTS; ++s) t_slot(sRb, cw[s], cl + (size_t)srow[s] * FEA_Q_THREADS, cnt[s], acc[s]);
+        for (int s = 0; s < FEA_Q_SLOTS; ++s) t_slot<NPE>(sRb, cw[s], cl + (size_t)srow[s] * FEA_Q_THREADS, cnt[s], acc[s]);
       }
       if (vlane) {
 #pragma unroll
         for (int k = 0; k < FEA_Q_REGW; ++k)
-          if (k < fdw) { t_visit<DOF>(sRb, sS, fw[k] & 0xFFFFu, kd, fa); t_visit<DOF>(sRb, sS, fw[k] >> 16, kd, fa); }
+          if (k < fdw) { t_visit<NPE, DOF>(sRb, sS, fw[k] & 0xFFFFu, kd, fa); t_visit<NPE, DOF>(sRb, sS, fw[k] >> 16, kd, fa); }
       }
       T_STAMP(3);
       if (g + 1 < G) T_BARRIER();                        // the records have been read
@@ -431,9 +436,9 @@ void k_assemble_gather10(G10Args A, int run_len)
 int ensure_gather10(feahip_ctx *c)
 {
   if (c->have_gather && c->gather10_lay && c->gather_row0 == c->row0 && c->gather_row1 == c->row1) return FEAHIP_OK;
-  if (c->gather_failed || !c->h_pat || c->h_conn.empty() || c->npe != 10 || c->G > T_GMAX) return FEAHIP_OK;
+  if (c->gather_failed || !c->h_pat || c->h_conn.empty() || (c->npe != 10 && c->npe != 8) || c->G > T_GMAX) return FEAHIP_OK;
   HostGather10 hg;
-  build_host_gather10(c->N, c->E, c->h_conn.data(), *c->h_pat, c->row0, c->row1, hg);
+  build_host_gather10(c->N, c->E, c->npe, c->h_conn.data(), *c->h_pat, c->row0, c->row1, hg);
   if (!hg.ok) { c->gather_failed = true; return FEAHIP_OK; }
   for (void *p : {(void *)c->d_gmaps, (void *)c->d_g10_elist, (void *)c->d_g10_state})
     if (p) (void)hipFree(p);
@@ -460,9 +465,9 @@ int ensure_gather10(feahip_ctx *c)
   return FEAHIP_OK;
 }
 
-static int gather10_lds_bytes(const Gather10Layout &lay, int G)
+static int gather10_lds_bytes(const Gather10Layout &lay, int G, int npe)
 {
-  return (G <= T_GLDS ? G * 40 * 8 : 0) + FEA_Q_FLANES * 9 * 8 + (lay.max_elems + 1) * 6 * 8 + 208 * 2 + (lay.max_elems + 1) * T_REC * 8;
+  return (G <= T_GLDS ? G * npe * 4 * 8 : 0) + FEA_Q_FLANES * 9 * 8 + (lay.max_elems + 1) * 6 * 8 + 208 * 2 + (lay.max_elems + 1) * T_RECD(npe) * 8;
 }
 
 int launch_assemble_gather10(feahip_ctx *c, bool doK, bool doF)
@@ -473,7 +478,10 @@ int launch_assemble_gather10(feahip_ctx *c, bool doK, bool doF)
     S.nloc = c->g10_nloc; S.G = c->G; S.model = c->model; S.row0 = c->row0; S.row1 = c->row1; S.lambda = c->lambda; S.mu = c->mu;
     S.tab = c->d_table; S.elist = c->d_g10_elist; S.conn = c->d_conn; S.X0 = c->d_X0; S.x = c->d_x;
     S.state = c->d_g10_state; S.bad = doK ? c->d_flag + 1 : nullptr;      // the counter is reset by stiffness assemblies only
-    if (c->g10_nloc > 0) hipLaunchKernelGGL(k_state10, dim3((unsigned)((c->g10_nloc + 255) / 256)), dim3(256), 0, c->stream, S);
+    if (c->g10_nloc > 0) {
+      if (c->npe == 10) hipLaunchKernelGGL(k_state10<10>, dim3((unsigned)((c->g10_nloc + 255) / 256)), dim3(256), 0, c->stream, S);
+      else              hipLaunchKernelGGL(k_state10<8>, dim3((unsigned)((c->g10_nloc + 255) / 256)), dim3(256), 0, c->stream, S);
+    }
   }
   G10Args A;
   A.nchunks = c->ngchunks; A.G = c->G; A.tab = c->d_table; A.maps = c->d_gmaps; A.lay = *c->gather10_lay;
@@ -491,26 +499,22 @@ int launch_assemble_gather10(feahip_ctx *c, bool doK, bool doF)
   if (run_len < 0) { const char *e = getenv("FEAHIP_GATHER10_RUN"); run_len = e && atoi(e) > 0 ? atoi(e) : 8; }
   const int nruns = (c->ngchunks + run_len - 1) / run_len;
   const dim3 grid((nruns + 7) & ~7), blk(FEA_Q_THREADS);
-  const int lds = gather10_lds_bytes(A.lay, c->G);
+  const int lds = gather10_lds_bytes(A.lay, c->G, c->npe);
   const bool tl = c->G <= T_GLDS;
-  const int variant = (!doK ? 2 : (doF ? 1 : 0)) * 2 + (tl ? 1 : 0);
-#define G10_KERNEL(K_, F_, T_) k_assemble_gather10<K_, F_, T_>
-  const void *fns[6] = {reinterpret_cast<const void *>(&G10_KERNEL(true, false, false)), reinterpret_cast<const void *>(&G10_KERNEL(true, false, true)),
-                        reinterpret_cast<const void *>(&G10_KERNEL(true, true, false)), reinterpret_cast<const void *>(&G10_KERNEL(true, true, true)),
-                        reinterpret_cast<const void *>(&G10_KERNEL(false, true, false)), reinterpret_cast<const void *>(&G10_KERNEL(false, true, true))};
+  const int variant = ((c->npe == 10 ? 0 : 1) * 3 + (!doK ? 2 : (doF ? 1 : 0))) * 2 + (tl ? 1 : 0);
+  typedef void (*g10_fn)(G10Args, int);
+#define G10_ROW(N_) k_assemble_gather10<N_, true, false, false>, k_assemble_gather10<N_, true, false, true>, k_assemble_gather10<N_, true, true, false>, \
+                    k_assemble_gather10<N_, true, true, true>, k_assemble_gather10<N_, false, true, false>, k_assemble_gather10<N_, false, true, true>
+  static const g10_fn fns[12] = {G10_ROW(10), G10_ROW(8)};
+#undef G10_ROW
   if (lds > 64 * 1024) {
-    static bool raised[6] = {false, false, false, false, false, false};
-    if (!raised[variant]) { FEA_HIP_CHECK(c, hipFuncSetAttribute(fns[variant], hipFuncAttributeMaxDynamicSharedMemorySize, lds)); raised[variant] = true; }
+    static bool raised[12] = {false, false, false, false, false, false, false, false, false, false, false, false};
+    if (!raised[variant]) {
+      FEA_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(fns[variant]), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      raised[variant] = true;
+    }
   }
-  switch (variant) {
-    case 0: hipLaunchKernelGGL((G10_KERNEL(true, false, false)), grid, blk, lds, c->stream, A, run_len); break;
-    case 1: hipLaunchKernelGGL((G10_KERNEL(true, false, true)), grid, blk, lds, c->stream, A, run_len); break;
-    case 2: hipLaunchKernelGGL((G10_KERNEL(true, true, false)), grid, blk, lds, c->stream, A, run_len); break;
-    case 3: hipLaunchKernelGGL((G10_KERNEL(true, true, true)), grid, blk, lds, c->stream, A, run_len); break;
-    case 4: hipLaunchKernelGGL((G10_KERNEL(false, true, false)), grid, blk, lds, c->stream, A, run_len); break;
-    default: hipLaunchKernelGGL((G10_KERNEL(false, true, true)), grid, blk, lds, c->stream, A, run_len); break;
-  }
-#undef G10_KERNEL
+  hipLaunchKernelGGL(fns[variant], grid, blk, lds, c->stream, A, run_len);
   FEA_HIP_CHECK(c, hipGetLastError());
 #ifdef FEAHIP_DEBUG
   if (A.stamps) {

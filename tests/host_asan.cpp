@@ -38,8 +38,8 @@ int main()
       HostQuad hq; build_host_quad(N, E, npe, conn.data(), hp, 0, na, hq);
       HostQuad hs; build_host_quad(N, E, npe, conn.data(), hp, na / 3, 2 * na / 3, hs);      // a rank's chunks only
       printf("tet10: N=%d E=%d chunks=%zu achunks=%zu quad=%d/%d pairs=%zu\n", N, E, hp.chunk.size() - 1, hp.achunk.size() - 1, (int)hq.ok, (int)hs.ok, hq.qpair.size());
-      HostGather10 g10; build_host_gather10(N, E, conn.data(), hp, 0, N, g10);
-      HostGather10 g10s; build_host_gather10(N, E, conn.data(), hp, N / 3, 2 * N / 3, g10s);      // a rank's rows only
+      HostGather10 g10; build_host_gather10(N, E, 10, conn.data(), hp, 0, N, g10);
+      HostGather10 g10s; build_host_gather10(N, E, 10, conn.data(), hp, N / 3, 2 * N / 3, g10s);      // a rank's rows only
       printf("tet10: gather10=%d/%d chunks=%d in %.2f chunks per element\n", (int)g10.ok, (int)g10s.ok, g10.nchunks,
              g10.distinct_elems ? (double)g10.total_evals / (double)g10.distinct_elems : 0.0);
     }

@@ -84,12 +84,16 @@ def test_hex8_assembly_matches_oracle(model):
     s, o = feahip.FeaSolver(deck), OracleSolver(deck)
     s.set_nodes(x); o.set_nodes(x)
     o.update_state(); o.create_stiffness(); o.create_residual_forces()
-    for strat in (feahip.ASM_AUTO, feahip.ASM_ROWOWNER, feahip.ASM_ATOMIC):
+    for strat in (feahip.ASM_AUTO, feahip.ASM_GATHER, feahip.ASM_ROWOWNER, feahip.ASM_ATOMIC):
         s.set_assembly(strat)
         s.create_stiffness_and_residual()
         off, idx, val = s.matrix_yale()
         assert np.array_equal(off, o.offsets()) and np.array_equal(idx, o.indexes())      # bit-exact indexing
         assert rel(val, o.values()) < 1e-12 and rel(s.forces(), o.forces()) < 1e-12, strat
+        if strat == feahip.ASM_AUTO:
+            assert s.assembly_in_use() == feahip.ASM_GATHER      # state kernel + gather kernel, as for 10-node tetrahedra
+        s.create_residual_forces()                               # the residual alone
+        assert rel(s.forces(), o.forces()) < 1e-12, strat
     assert s.assembly_in_use() == feahip.ASM_ATOMIC
     assert rel(s.graddefs(), o.graddefs()) < 1e-13 and rel(s.stresses(), o.stresses()) < 1e-12
     g, d = s.shape_gradients()
