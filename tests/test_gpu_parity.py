@@ -594,3 +594,48 @@ def test_node_with_more_neighbours_than_the_spmv_tile():
     with pytest.raises(feahip.FeaHipError, match="block rows of at most 128"):
         s.solve_slae(feahip.PCG_ILU, 1e-12, 100)
     s.close(); o.close()
+
+
+def test_tet10_hub_node_beyond_every_chunk_limit():
+    """A quadratic fan: 140 ten-node tetrahedra around one node (more than the 127 element records of a gather chunk,
+    its block row longer than the K tile).  The gather and shared-state maps do not build for this mesh; AUTO must end
+    at a kernel that assembles it correctly, and an explicit GATHER request must be refused, not replaced."""
+    m = 70
+    ang = 2 * np.pi * np.arange(m) / m
+    ring = np.stack([np.cos(ang), np.sin(ang), np.zeros(m)], axis=1)
+    corners = np.vstack([[0.0, 0.0, 0.0], ring, [0.0, 0.0, 0.7], [0.0, 0.0, -0.7]])
+    top, bot = m + 1, m + 2
+    el4 = []
+    for i in range(m):
+        a, b = 1 + i, 1 + (i + 1) % m
+        el4.append([0, a, b, top])
+        el4.append([0, b, a, bot])
+    nodes = [tuple(c) for c in corners]
+    mid = {}
+    el = []
+    for e in el4:
+        row = list(e)
+        for (i, j) in mesh._EDGES:
+            key = (min(e[i], e[j]), max(e[i], e[j]))
+            if key not in mid:
+                mid[key] = len(nodes)
+                nodes.append(tuple(0.5 * (corners[key[0]] + corners[key[1]])))
+            row.append(mid[key])
+        el.append(row)
+    nodes = np.array(nodes)
+    deck = feahip.Deck(nodes=nodes, elements=np.array(el, dtype=np.int32), ele_type=feahip.TETRAHEDRA10, gauss_nodes_count=5,
+                       presc_node=[top, bot], presc_type=[7, 7], presc_values=np.zeros((2, 3)))
+    x = nodes * np.array([1.02, 0.99, 1.05]) + 1e-3 * np.sin(3 * nodes[:, [1, 2, 0]])
+    s, o = make_pair(deck, x)
+    o.update_state(); o.create_stiffness(); o.create_residual_forces()
+    s.create_stiffness_and_residual()
+    assert s.assembly_in_use() not in (feahip.ASM_GATHER, feahip.ASM_SHARED)
+    off, idx, val = s.matrix_yale()
+    assert np.array_equal(off, o.offsets()) and np.array_equal(idx, o.indexes())
+    assert rel(val, o.values()) < K_TOL and rel(s.forces(), o.forces()) < K_TOL
+    s.create_residual_forces()
+    assert rel(s.forces(), o.forces()) < K_TOL
+    s.set_assembly(feahip.ASM_GATHER)
+    with pytest.raises(feahip.FeaHipError, match="gather assembly"):
+        s.create_stiffness_and_residual()
+    s.close(); o.close()
