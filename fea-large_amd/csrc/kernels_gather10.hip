@@ -496,7 +496,7 @@ int launch_assemble_gather10(feahip_ctx *c, bool doK, bool doF)
   }
 #endif
   static int run_len = -1;           // chunks per workgroup run (FEAHIP_GATHER10_RUN: tuning only, results unchanged)
-  if (run_len < 0) { const char *e = getenv("FEAHIP_GATHER10_RUN"); run_len = e && atoi(e) > 0 ? atoi(e) : 8; }
+  if (run_len < 0) { const char *e = getenv("FEAHIP_GATHER10_RUN"); run_len = e && atoi(e) > 0 ? atoi(e) : 2; }
   const int nruns = (c->ngchunks + run_len - 1) / run_len;
   const dim3 grid((nruns + 7) & ~7), blk(FEA_Q_THREADS);
   const int lds = gather10_lds_bytes(A.lay, c->G, c->npe);
