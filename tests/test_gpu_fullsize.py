@@ -96,14 +96,16 @@ def test_1m_multigrid_newton_step_equals_block_jacobi(block_1m):
     assert np.abs(u1 - u0).max() < 1e-10 * np.abs(u0).max()
 
 
-def test_500k_tet10_shared_state_assembly_properties():
-    """configs[4] element (10-node, here 5 points): the shared-state kernel
-    on 497 664 elements agrees with the generic row-owner kernel, and K is
-    symmetric and translation-free."""
-    deck = mesh.bar_deck(n=24, quadratic=True)
+@pytest.mark.parametrize("brick", [None, (3, 4, 4)])
+def test_500k_tet10_assembly_properties(brick):
+    """configs[4] element (10-node, here 5 points) on 497 664 elements, lexicographic and brick numbering: what AUTO
+    runs (the state + gather kernels) agrees with the shared-state kernel and with the generic row-owner kernel, K is
+    symmetric and translation-free, and the residual alone equals the residual of the fused assembly."""
+    deck = mesh.bar_deck(n=24, quadratic=True, brick=brick)
     s = feahip.FeaSolver(deck)
     s.set_nodes(mesh.deformed_state(deck.nodes))
-    s.create_stiffness_and_residual()                    # AUTO = shared-state kernel
+    s.set_assembly(feahip.ASM_GATHER)                     # AUTO takes it for the brick numbering only (lexicographic ids: an
+    s.create_stiffness_and_residual()                     # element in > 6 chunks, AUTO stays with the shared-state kernel)
     assert s.update_state() == 0
     rng = np.random.default_rng(11)
     a, b = rng.normal(size=s.ndof), rng.normal(size=s.ndof)
@@ -111,11 +113,16 @@ def test_500k_tet10_shared_state_assembly_properties():
     t = np.zeros(s.ndof); t[2::3] = 1.0
     assert np.abs(s.spmv(t)).max() < 1e-11 * np.abs(ya).max()
     assert abs(b @ ya - a @ s.spmv(b)) < 1e-11 * abs(b @ ya)
-    s.set_assembly(feahip.ASM_ROWOWNER)
-    s.create_stiffness_and_residual()
-    assert np.abs(s.spmv(a) - ya).max() < 1e-12 * np.abs(ya).max()
+    s.create_residual_forces()
     # f is a sum of element contributions ~100x its own size here (near equilibrium): 1e-11 of max|f|
     assert np.abs(s.forces() - f0).max() < 1e-11 * np.abs(f0).max()
+    for strat in (feahip.ASM_AUTO, feahip.ASM_SHARED, feahip.ASM_ROWOWNER):
+        s.set_assembly(strat)
+        s.create_stiffness_and_residual()
+        if strat == feahip.ASM_AUTO:
+            assert s.assembly_in_use() == (feahip.ASM_GATHER if brick else feahip.ASM_SHARED)
+        assert np.abs(s.spmv(a) - ya).max() < 1e-12 * np.abs(ya).max()
+        assert np.abs(s.forces() - f0).max() < 1e-11 * np.abs(f0).max()
     s.close()
 
 
@@ -156,7 +163,7 @@ def test_1m_lame_cylinder_a5_sharded_equals_unsharded():
 
 def test_tet10_27_point_rule_at_scale():
     """configs[4] element and rule (10-node, 27 Gauss points) on 165 888
-    elements: shared-state kernel = generic kernel, K symmetric, and the
+    elements: what AUTO runs (state + gather kernels) = generic kernel, K symmetric, and the
     27-point K equals the 5-point K to the accuracy of the quadrature on this
     smooth state (both rules integrate the same polynomial tangent exactly
     to O(h^2) here)."""
