@@ -544,14 +544,14 @@ extern "C" int feahip_host_assembly_digest(int n_nodes, int n_elems, int npe, co
     gather_row_digest(hg, hp, rowhash);
   } else {
     // what AUTO runs for 10-node elements (kernels_assemble.hip): the gather maps when they build and an element
-    // is not evaluated by too many chunks, the shared-state maps otherwise.  Both list every off-diagonal
+    // does not fall into too many chunks (12), the shared-state maps otherwise.  Both list every off-diagonal
     // contribution (the gather maps' mirror blocks are expanded); neither digest covers the diagonal blocks.
     bool done = false;
     if (npe == 10 || npe == 8) {
       HostGather10 hg;
       hash_npe = npe;
       build_host_gather10(n_nodes, n_elems, npe, elements, hp, row0, row1, hg);
-      if (hg.ok && (double)hg.total_evals <= 6.0 * (double)hg.distinct_elems) {
+      if (hg.ok && (double)hg.total_evals <= 12.0 * (double)hg.distinct_elems) {
         gather10_row_digest(hg, hp, elements, rowhash, contribution_hash10);
         done = true;
       }

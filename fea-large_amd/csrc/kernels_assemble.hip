@@ -321,10 +321,10 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
     }
     if (strat == FEAHIP_ASM_AUTO && (c->npe == 10 || c->npe == 8)) {
       // 10-node tetrahedra, 8-node bricks: gather chunks of up to 64 rows where the numbering keeps them compact (an element's
-      // records are expanded in ~3 chunks with a brick numbering; lexicographic ids: ~5, still ahead of the 3-row
-      // chunks of the shared-state kernel, which evaluate an element 8 times)
+      // records are expanded in ~3 chunks with a brick numbering; lexicographic ids on the 497 664-element block: ~7
+      // chunks, 1.42 ms against the 2.27 of the shared-state kernel, whose 3-row chunks evaluate an element 8 times)
       { const int rc = ensure_gather10(c); if (rc) return rc; }
-      if (c->have_gather && c->gather_evals_per_element <= 6.0) strat = FEAHIP_ASM_GATHER;
+      if (c->have_gather && c->gather_evals_per_element <= 12.0) strat = FEAHIP_ASM_GATHER;
     }
     if (strat == FEAHIP_ASM_AUTO && c->npe == 10) { const int rc = ensure_quad(c); if (rc) return rc; }
     if (strat == FEAHIP_ASM_AUTO)

@@ -104,8 +104,8 @@ def test_500k_tet10_assembly_properties(brick):
     deck = mesh.bar_deck(n=24, quadratic=True, brick=brick)
     s = feahip.FeaSolver(deck)
     s.set_nodes(mesh.deformed_state(deck.nodes))
-    s.set_assembly(feahip.ASM_GATHER)                     # AUTO takes it for the brick numbering only (lexicographic ids: an
-    s.create_stiffness_and_residual()                     # element in > 6 chunks, AUTO stays with the shared-state kernel)
+    s.create_stiffness_and_residual()
+    assert s.assembly_in_use() == feahip.ASM_GATHER       # AUTO, either numbering (lexicographic ids: an element in ~7 chunks)
     assert s.update_state() == 0
     rng = np.random.default_rng(11)
     a, b = rng.normal(size=s.ndof), rng.normal(size=s.ndof)
@@ -116,11 +116,9 @@ def test_500k_tet10_assembly_properties(brick):
     s.create_residual_forces()
     # f is a sum of element contributions ~100x its own size here (near equilibrium): 1e-11 of max|f|
     assert np.abs(s.forces() - f0).max() < 1e-11 * np.abs(f0).max()
-    for strat in (feahip.ASM_AUTO, feahip.ASM_SHARED, feahip.ASM_ROWOWNER):
+    for strat in (feahip.ASM_SHARED, feahip.ASM_ROWOWNER):
         s.set_assembly(strat)
         s.create_stiffness_and_residual()
-        if strat == feahip.ASM_AUTO:
-            assert s.assembly_in_use() == (feahip.ASM_GATHER if brick else feahip.ASM_SHARED)
         assert np.abs(s.spmv(a) - ya).max() < 1e-12 * np.abs(ya).max()
         assert np.abs(s.forces() - f0).max() < 1e-11 * np.abs(f0).max()
     s.close()
