@@ -280,7 +280,8 @@ void k_assemble_gather10(G10Args A, int run_len)
 #ifdef FEAHIP_DEBUG
       if (A.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); T_STAMP(7); }
 #endif
-      if (xact) {
+      __builtin_amdgcn_s_setprio(2);                     // wave priorities by phase: the short LDS-bound expand ahead of the other
+      if (xact) {                                        // workgroup's long gather (0), the write-out ahead of both (3): 1 %
         const double2 (&h)[T_HDR / 2] = hn;
         const double vl = h[7].y, vm = h[8].x;
         double *r = sR + xe * T_REC;
@@ -323,6 +324,7 @@ void k_assemble_gather10(G10Args A, int run_len)
       T_STAMP(1);
       T_BARRIER();
       T_STAMP(2);
+      __builtin_amdgcn_s_setprio(0);
       // ---- gather: this thread's blocks; the visit lanes' diagonal blocks and residuals
       // (the list words are made opaque per Gauss point: hoisted out of this loop, the LDS addresses decoded from them
       // -- some 200 registers' worth -- were spilled to scratch and reloaded here)
@@ -346,6 +348,7 @@ void k_assemble_gather10(G10Args A, int run_len)
       T_STAMP(4);
     }
     // ---- write-out
+    __builtin_amdgcn_s_setprio(3);
     if (vlane) {
       double *o = sFp + fl * 9;
       o[0] = kd[0]; o[1] = kd[1]; o[2] = kd[2]; o[3] = kd[3]; o[4] = kd[4]; o[5] = kd[5];
