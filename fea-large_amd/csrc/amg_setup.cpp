@@ -122,8 +122,6 @@ static bool build_levels(const std::vector<int> &rowptr0, const std::vector<int>
   for (;;) {
     const int N = L.N, S = L.S;
     const bool paired = (N == 2 * S);                                      // false only on level 0
-    for (int a = 0; a < N; ++a)
-      if (L.rowptr[a + 1] - L.rowptr[a] > FEA_CHUNK_BLOCKS) return false;  // SpMV chunk limit
     finish_pattern(L);
     if (N <= 1500 || out.size() >= 6) { L.Sc = 0; out.push_back(L); break; }
     int nagg = 0;

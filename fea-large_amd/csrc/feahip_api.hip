@@ -4,11 +4,16 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
+#include <utility>
 
 static std::string g_create_error;
 
 extern "C" const char *feahip_create_error(void) { return g_create_error.c_str(); }
 extern "C" const char *feahip_last_error(const feahip_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+// library id of a caller's node
+static inline int lib_id(const feahip_ctx *c, int a) { return c->perm.empty() ? a : c->perm[a]; }
 
 template <class T>
 static int dev_upload(feahip_ctx *c, T **dst, const T *src, size_t n)
@@ -62,19 +67,23 @@ int ensure_k(feahip_ctx *c)
 {
   if (c->d_K_base) return FEAHIP_OK;
   c->kb0 = c->h_rowptr[c->row0]; c->kb1 = c->h_rowptr[c->row1];
-  const size_t n = (size_t)(c->kb1 - c->kb0) * 9 + 2;       // +2: the SpMV reads aligned 80-byte windows
-  FEA_HIP_CHECK(c, hipMalloc((void **)&c->d_K_base, sizeof(double) * n));
+  // +2: the SpMV reads aligned 80-byte windows; +1: a shard whose first block is odd starts one double into the
+  // allocation, so that EVEN global value indices are 16-byte aligned on every rank (the gather kernels pick the
+  // alignment of their 16-byte row stores from the parity of the chunk's first global block)
+  const size_t n = (size_t)(c->kb1 - c->kb0) * 9 + 3;
+  FEA_HIP_CHECK(c, hipMalloc((void **)&c->d_K_alloc, sizeof(double) * n));
   // on the context's own (non-blocking) stream: a null-stream memset is not ordered against the kernels that follow
-  FEA_HIP_CHECK(c, hipMemsetAsync(c->d_K_base, 0, sizeof(double) * n, c->stream));
+  FEA_HIP_CHECK(c, hipMemsetAsync(c->d_K_alloc, 0, sizeof(double) * n, c->stream));
+  c->d_K_base = c->d_K_alloc + (c->kb0 & 1);
   c->d_K = c->d_K_base - (size_t)c->kb0 * 9;
   return FEAHIP_OK;
 }
 
 void release_k(feahip_ctx *c)
 {
-  if (c->d_K_base) (void)hipFree(c->d_K_base);
-  if (c->d_Kstash_base) (void)hipFree(c->d_Kstash_base);
-  c->d_K_base = c->d_Kstash_base = c->d_K = c->d_Kstash = nullptr;
+  if (c->d_K_alloc) (void)hipFree(c->d_K_alloc);
+  if (c->d_Kstash_alloc) (void)hipFree(c->d_Kstash_alloc);
+  c->d_K_alloc = c->d_Kstash_alloc = c->d_K_base = c->d_Kstash_base = c->d_K = c->d_Kstash = nullptr;
   c->have_stash = false; c->k_bc = false; ++c->k_epoch;
 }
 
@@ -161,6 +170,40 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
 
   c->N = n_nodes; c->E = n_elems; c->npe = npe; c->G = gauss_count; c->ndof = 3 * n_nodes;
   c->model = model; c->lambda = model_params[0]; c->mu = model_params[1];
+
+  // ---- the library's own node numbering (renumber.cpp).  From here on `elements`, `nodes0` and `presc_node` are
+  // the permuted copies; the caller's ids come back at the getters.  FEAHIP_RENUMBER=0 keeps the caller's numbering
+  // (measurement knob: what the kernels make of the ids as given).
+  std::vector<int> elements_p, presc_p;
+  std::vector<double> nodes_p;
+  {
+    for (long long i = 0; i < (long long)n_elems * npe; ++i)
+      if (elements[i] < 0 || elements[i] >= n_nodes) {
+        c->err = "element " + std::to_string(i / npe) + " refers to node " + std::to_string(elements[i]) + " outside [0," + std::to_string(n_nodes) + ")";
+        return FEAHIP_EINVAL;
+      }
+    const char *e = getenv("FEAHIP_RENUMBER");
+    if (!(e && atoi(e) == 0) && locality_numbering(n_nodes, n_elems, npe, elements, nodes0, c->perm)) {
+      bool identity = true;
+      for (int a = 0; a < n_nodes && identity; ++a) identity = c->perm[a] == a;
+      if (identity) c->perm.clear();
+    } else c->perm.clear();
+    if (!c->perm.empty()) {
+      c->iperm.resize((size_t)n_nodes);
+      for (int a = 0; a < n_nodes; ++a) c->iperm[c->perm[a]] = a;
+      elements_p.resize((size_t)n_elems * npe);
+      for (size_t i = 0; i < elements_p.size(); ++i) elements_p[i] = c->perm[elements[i]];
+      nodes_p.resize((size_t)n_nodes * 3);
+      for (int a = 0; a < n_nodes; ++a)
+        for (int j = 0; j < 3; ++j) nodes_p[(size_t)c->perm[a] * 3 + j] = nodes0[(size_t)a * 3 + j];
+      presc_p.resize((size_t)n_presc);
+      for (int i = 0; i < n_presc; ++i) {
+        if (presc_node[i] < 0 || presc_node[i] >= n_nodes) { c->err = "prescribed node id out of range"; return FEAHIP_EINVAL; }
+        presc_p[i] = c->perm[presc_node[i]];
+      }
+      elements = elements_p.data(); nodes0 = nodes_p.data(); presc_node = presc_p.data();
+    }
+  }
 
   memset(&c->table, 0, sizeof(c->table));
   for (int g = 0; g < gauss_count; ++g) {
@@ -281,7 +324,7 @@ extern "C" void feahip_destroy(feahip_ctx *c)
   delete c->h_pat; c->h_pat = nullptr;
   delete c->gather_lay; c->gather_lay = nullptr;
   delete c->gather10_lay; c->gather10_lay = nullptr;
-  void *ptrs[] = {(void *)c->d_gmaps, (void *)c->d_g10_elist, (void *)c->d_g10_state, c->d_table, c->d_conn, c->d_X0, c->d_x, c->d_rowptr, c->d_colidx, c->d_K_base, c->d_Kstash_base,
+  void *ptrs[] = {(void *)c->d_gmaps, (void *)c->d_g10_elist, (void *)c->d_g10_state, c->d_table, c->d_conn, c->d_X0, c->d_x, c->d_rowptr, c->d_colidx, c->d_K_alloc, c->d_Kstash_alloc,
                   c->d_incptr, c->d_inc, c->d_incslot, c->d_chunk, c->d_diag, c->d_pdesc, c->d_pnode, c->d_pelem, c->d_pent, c->d_pbptr, c->d_vdesc, c->d_vnode, c->d_vrec, c->d_pairdesc, c->d_prec, c->d_qdesc, c->d_qelem, c->d_qpair, c->d_qnode, c->d_f, c->d_u, c->d_r, c->d_p,
                   c->d_q, c->d_minv, c->d_part, c->d_scal, c->d_flag, c->d_cdof, c->d_cval,
                   c->d_dofmask, c->d_F, c->d_S};
@@ -369,7 +412,8 @@ extern "C" int feahip_stash_stiffness(feahip_ctx *c)
   CTX_GUARD(c);
   const size_t bytes = sizeof(double) * 9 * (size_t)(c->kb1 - c->kb0);
   if (!c->d_Kstash_base) {
-    FEA_HIP_CHECK(c, hipMalloc((void **)&c->d_Kstash_base, bytes ? bytes : 8));
+    FEA_HIP_CHECK(c, hipMalloc((void **)&c->d_Kstash_alloc, bytes + 8));
+    c->d_Kstash_base = c->d_Kstash_alloc + (c->kb0 & 1);      // same 16-byte phase as K
     c->d_Kstash = c->d_Kstash_base - (size_t)c->kb0 * 9;
   }
   FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_Kstash_base, c->d_K_base, bytes, hipMemcpyDeviceToDevice, c->stream));
@@ -410,6 +454,13 @@ extern "C" int feahip_update_nodes_with_solution(feahip_ctx *c, const double *u)
 {
   CTX_GUARD(c);
   std::vector<feahip_ctx *> R(1, c);
+  std::vector<double> tmp;
+  if (u && !c->perm.empty()) {
+    tmp.resize((size_t)c->ndof);
+    for (int a = 0; a < c->N; ++a)
+      for (int j = 0; j < 3; ++j) tmp[(size_t)c->perm[a] * 3 + j] = u[(size_t)a * 3 + j];
+    u = tmp.data();
+  }
   return dist_update_nodes_with_solution(R, u);
 }
 
@@ -541,6 +592,18 @@ extern "C" int feahip_shard_plan(int n_nodes, int n_elems, int npe, const int *e
   return FEAHIP_OK;
 }
 
+extern "C" int feahip_host_numbering(int n_nodes, int n_elems, int npe, const int *elements, const double *nodes0, int *library_id_of_node)
+{
+  if (!elements || !nodes0 || !library_id_of_node || n_nodes <= 0 || n_elems <= 0 || (npe != 4 && npe != 8 && npe != 10)) return FEAHIP_EINVAL;
+  for (long long i = 0; i < (long long)n_elems * npe; ++i)
+    if (elements[i] < 0 || elements[i] >= n_nodes) return FEAHIP_EINVAL;
+  std::vector<int> perm;
+  const bool any = locality_numbering(n_nodes, n_elems, npe, elements, nodes0, perm);
+  bool identity = true;
+  for (int a = 0; a < n_nodes; ++a) { library_id_of_node[a] = perm[a]; identity = identity && perm[a] == a; }
+  return any && !identity ? 1 : 0;
+}
+
 // ---- views ---------------------------------------------------------------
 
 extern "C" int feahip_set_nodes(feahip_ctx *c, const double *nodes)
@@ -549,7 +612,7 @@ extern "C" int feahip_set_nodes(feahip_ctx *c, const double *nodes)
   if (!nodes) return FEAHIP_EINVAL;
   std::vector<double> pad((size_t)c->N * 4, 0.0);
   for (int a = 0; a < c->N; ++a)
-    for (int j = 0; j < 3; ++j) pad[(size_t)a * 4 + j] = nodes[(size_t)a * 3 + j];
+    for (int j = 0; j < 3; ++j) pad[(size_t)lib_id(c, a) * 4 + j] = nodes[(size_t)a * 3 + j];
   FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_x, pad.data(), sizeof(double) * pad.size(), hipMemcpyHostToDevice, c->stream));
   FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
   c->state_valid = false;
@@ -564,7 +627,7 @@ extern "C" int feahip_get_nodes(feahip_ctx *c, double *nodes)
   FEA_HIP_CHECK(c, hipMemcpyAsync(pad.data(), c->d_x, sizeof(double) * pad.size(), hipMemcpyDeviceToHost, c->stream));
   FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
   for (int a = 0; a < c->N; ++a)
-    for (int j = 0; j < 3; ++j) nodes[(size_t)a * 3 + j] = pad[(size_t)a * 4 + j];
+    for (int j = 0; j < 3; ++j) nodes[(size_t)a * 3 + j] = pad[(size_t)lib_id(c, a) * 4 + j];
   return FEAHIP_OK;
 }
 
@@ -576,15 +639,42 @@ static int get_vec(feahip_ctx *c, const double *d, double *h, size_t n)
   return FEAHIP_OK;
 }
 
-extern "C" int feahip_get_forces(feahip_ctx *c, double *f) { CTX_GUARD(c); return get_vec(c, c->d_f, f, (size_t)c->ndof); }
-extern "C" int feahip_get_solution(feahip_ctx *c, double *u) { CTX_GUARD(c); return get_vec(c, c->d_u, u, (size_t)c->ndof); }
-
-extern "C" int feahip_set_forces(feahip_ctx *c, const double *f)
+// node vectors (3 doubles per node) between the caller's numbering (host) and the library's (device)
+static int get_node_vec(feahip_ctx *c, const double *d, double *h)
 {
-  CTX_GUARD(c);
-  if (!f) return FEAHIP_EINVAL;
-  FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_f, f, sizeof(double) * (size_t)c->ndof, hipMemcpyHostToDevice, c->stream));
+  if (c->perm.empty()) return get_vec(c, d, h, (size_t)c->ndof);
+  if (!h) return FEAHIP_EINVAL;
+  std::vector<double> tmp((size_t)c->ndof);
+  const int rc = get_vec(c, d, tmp.data(), tmp.size());
+  if (rc) return rc;
+  for (int a = 0; a < c->N; ++a)
+    for (int j = 0; j < 3; ++j) h[(size_t)a * 3 + j] = tmp[(size_t)c->perm[a] * 3 + j];
+  return FEAHIP_OK;
+}
+
+static int set_node_vec(feahip_ctx *c, double *d, const double *h)
+{
+  if (!h) return FEAHIP_EINVAL;
+  std::vector<double> tmp;
+  if (!c->perm.empty()) {
+    tmp.resize((size_t)c->ndof);
+    for (int a = 0; a < c->N; ++a)
+      for (int j = 0; j < 3; ++j) tmp[(size_t)c->perm[a] * 3 + j] = h[(size_t)a * 3 + j];
+    h = tmp.data();
+  }
+  FEA_HIP_CHECK(c, hipMemcpyAsync(d, h, sizeof(double) * (size_t)c->ndof, hipMemcpyHostToDevice, c->stream));
   FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+  return FEAHIP_OK;
+}
+
+extern "C" int feahip_get_forces(feahip_ctx *c, double *f) { CTX_GUARD(c); return get_node_vec(c, c->d_f, f); }
+extern "C" int feahip_get_solution(feahip_ctx *c, double *u) { CTX_GUARD(c); return get_node_vec(c, c->d_u, u); }
+extern "C" int feahip_set_forces(feahip_ctx *c, const double *f) { CTX_GUARD(c); return set_node_vec(c, c->d_f, f); }
+
+extern "C" int feahip_node_numbering(feahip_ctx *c, int *library_id_of_node)
+{
+  if (!c || !library_id_of_node) return FEAHIP_EINVAL;
+  for (int a = 0; a < c->N; ++a) library_id_of_node[a] = lib_id(c, a);
   return FEAHIP_OK;
 }
 
@@ -653,16 +743,23 @@ extern "C" int feahip_get_matrix_yale(feahip_ctx *c, int *offsets, int *indexes,
   if (rc) return rc;
   int pos = 0;
   offsets[0] = 0;
-  for (int a = 0; a < c->N; ++a)
+  std::vector<std::pair<int, int>> row;                           // (caller's column node, block) of one row, sorted by column
+  for (int a = 0; a < c->N; ++a) {                                // a: the CALLER's node; its row lives at the library id
+    const int la = lib_id(c, a);
+    row.clear();
+    for (int q = c->h_rowptr[la]; q < c->h_rowptr[la + 1]; ++q)
+      row.emplace_back(c->iperm.empty() ? c->h_colidx[q] : c->iperm[c->h_colidx[q]], q);
+    if (!c->iperm.empty()) std::sort(row.begin(), row.end());
     for (int i = 0; i < 3; ++i) {
-      for (int q = c->h_rowptr[a]; q < c->h_rowptr[a + 1]; ++q)
+      for (const auto &cb : row)
         for (int j = 0; j < 3; ++j) {
-          indexes[pos] = 3 * c->h_colidx[q] + j;
-          values[pos] = K[(size_t)q * 9 + 3 * i + j];
+          indexes[pos] = 3 * cb.first + j;
+          values[pos] = K[(size_t)cb.second * 9 + 3 * i + j];
           pos++;
         }
       offsets[3 * a + i + 1] = pos;
     }
+  }
   return FEAHIP_OK;
 }
 
@@ -670,11 +767,11 @@ extern "C" int feahip_spmv(feahip_ctx *c, const double *x, double *y)
 {
   CTX_GUARD(c);
   if (!x || !y) return FEAHIP_EINVAL;
-  FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_p, x, sizeof(double) * (size_t)c->ndof, hipMemcpyHostToDevice, c->stream));
-  FEA_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-  int rc = launch_spmv(c, c->d_p, c->d_q);
+  int rc = set_node_vec(c, c->d_p, x);
   if (rc) return rc;
-  return get_vec(c, c->d_q, y, (size_t)c->ndof);
+  rc = launch_spmv(c, c->d_p, c->d_q);
+  if (rc) return rc;
+  return get_node_vec(c, c->d_q, y);
 }
 
 extern "C" int feahip_time_kernel(feahip_ctx *c, int what, int warmup, int iters, double *avg_ms)

@@ -69,7 +69,8 @@ struct feahip_ctx {
   // and its modified-Newton copy, :179).  Kernels index by GLOBAL block number through d_K = d_K_base - 9 kb0.
   double *d_K = nullptr;       // [nnzb][3][3], valid for blocks [kb0, kb1) only
   double *d_Kstash = nullptr;  // modified-Newton copy (fea_solver.c:179), same window
-  double *d_K_base = nullptr, *d_Kstash_base = nullptr;   // the allocations
+  double *d_K_base = nullptr, *d_Kstash_base = nullptr;   // first owned value (block kb0) of each
+  double *d_K_alloc = nullptr, *d_Kstash_alloc = nullptr; // the allocations: d_K_base = d_K_alloc + (kb0 & 1), so that even GLOBAL value indices are 16-byte aligned on every rank
   long long kb0 = 0, kb1 = 0;
   bool have_stash = false;
   // node -> element incidence (row-owner assembly)
@@ -98,7 +99,9 @@ struct feahip_ctx {
   int *d_qnode = nullptr;
   long long quad_bytes = 0;
   // GATHER assembly maps (linear tetrahedra, kernels_gather.hip): built for the rows this rank owns
-  bool have_gather = false, gather_failed = false;
+  bool have_gather = false, gather_failed = false;   // gather_failed: the maps did not build for rows [gather_fail_row0, gather_fail_row1)
+  int gather_fail_row0 = -1, gather_fail_row1 = -1;
+  int gather_declined_row0 = -1, gather_declined_row1 = -1;   // AUTO looked at the gather chunks of these rows and chose another kernel (linear tets)
   int gather_row0 = -1, gather_row1 = -1, ngchunks = 0;
   unsigned char *d_gmaps = nullptr;
   struct GatherLayout *gather_lay = nullptr;
@@ -141,6 +144,10 @@ struct feahip_ctx {
   long long aux_bytes = 0;
 
   int last_bad = 0;
+
+  // library-side node numbering (renumber.cpp): everything in the context -- mesh arrays, pattern, K, vectors, shard
+  // ranges -- lives in the library's numbering; the ABI translates at its boundary.  Empty = the caller's numbering.
+  std::vector<int> perm, iperm;        // perm[caller id] = library id, iperm = its inverse
 
   // preconditioner of PCG_ILU / CHOLESKY solves: 0 = 3x3 block-Jacobi, 1 = aggregation multigrid (amg.h)
   // which matrix d_K holds: bumped by every stiffness assembly, copied by stash / restore; k_bc = prescribed-dof
@@ -281,6 +288,8 @@ struct HostGather {
 void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int row_lo, int row_hi, HostGather &out);
 int ensure_gather(feahip_ctx *c);
 int launch_assemble_gather(feahip_ctx *c, bool doK, bool doF);
+bool gather_pc_fits(const feahip_ctx *c);                      // kernels_gather_pc.hip: producer / consumer waves, one workgroup per CU
+int launch_assemble_gather_pc(feahip_ctx *c, bool doF);
 
 // GATHER assembly of 10-node tetrahedra (kernels_gather10.hip, gather10.cpp).  Same idea as the 4-node one with the
 // Gauss points as an outer loop: a 256-thread workgroup owns up to 64 consecutive block rows, evaluates every
@@ -351,6 +360,9 @@ int launch_spmv(feahip_ctx *c, const double *d_xv, double *d_yv);
 int solve_pcg(feahip_ctx *c, int type, double tol, int max_iter, int *iters,
               double *resid);
 int time_pcg_iteration(feahip_ctx *c, int warmup, int iters, double *avg_ms);
+
+// renumber.cpp -- locality numbering of the nodes; false = no basis for one (identity returned)
+bool locality_numbering(int N, int E, int npe, const int *conn, const double *X, std::vector<int> &new_of_old);
 
 // shard.cpp -- host-only plan of a row-sharded solve
 struct ShardPlan {

@@ -355,10 +355,18 @@ __device__ __forceinline__ double fd_log(double x)
   if (m < 0.70710678118654752) { m += m; e -= 1; }
   const double s = (m - 1.0) * fd_rcp(m + 1.0);
   const double z = s * s;
-  double p = 1.0 / 21.0;
-  p = fma(p, z, 1.0 / 19.0); p = fma(p, z, 1.0 / 17.0); p = fma(p, z, 1.0 / 15.0);
-  p = fma(p, z, 1.0 / 13.0); p = fma(p, z, 1.0 / 11.0); p = fma(p, z, 1.0 / 9.0);
-  p = fma(p, z, 1.0 / 7.0);  p = fma(p, z, 1.0 / 5.0);  p = fma(p, z, 1.0 / 3.0);
+  // The coefficients are pinned to scalar registers: left to itself the compiler turns p = fma(p, z, c) into
+  // v_fmac with c copied to a vector register, hoists the ten copies out of the caller's loop and, in a kernel
+  // short of vector registers, spills them -- ten scratch reloads inside the state evaluation, each waiting for
+  // every global load in flight (in-order counter).  v_fma_f64 takes a scalar pair as its addend.
+#define FD_SC(name, v) double name = (v); asm("" : "+s"(name))
+  FD_SC(c21, 1.0 / 21.0); FD_SC(c19, 1.0 / 19.0); FD_SC(c17, 1.0 / 17.0); FD_SC(c15, 1.0 / 15.0); FD_SC(c13, 1.0 / 13.0);
+  FD_SC(c11, 1.0 / 11.0); FD_SC(c9, 1.0 / 9.0); FD_SC(c7, 1.0 / 7.0); FD_SC(c5, 1.0 / 5.0); FD_SC(c3, 1.0 / 3.0);
+#undef FD_SC
+  double p = c21;
+  p = fma(p, z, c19); p = fma(p, z, c17); p = fma(p, z, c15);
+  p = fma(p, z, c13); p = fma(p, z, c11); p = fma(p, z, c9);
+  p = fma(p, z, c7);  p = fma(p, z, c5);  p = fma(p, z, c3);
   p = fma(p, z, 1.0);
   const double lnm = 2.0 * s * p;
   const double ed = (double)e;

@@ -1,0 +1,354 @@
+// gather_device.h -- device helpers shared by the GATHER assembly kernels of linear tetrahedra
+// (kernels_gather.hip: four phases per chunk, three workgroups per CU; kernels_gather_pc.hip: producer and
+// consumer waves, one workgroup per CU): the element record and its LDS layout, one contribution to a block,
+// the map words a thread holds.  Algebra of fem_device.h; replaces fea_solver.c:873-883, :887-1068, :1072-1114
+// for TETRAHEDRA4 meshes.
+#pragma once
+#include "fem_device.h"
+// Wave priorities by phase: a workgroup closer to the end of its chunk goes first.  Three workgroups share a CU and are
+// in different phases at any time; with equal priorities the latency-bound state phase of one took issue slots from the
+// tile writes and row stores of another, which is what releases LDS and the barrier for the next chunk: 3 % faster.
+#define PRIO_STATE 0
+#define PRIO_GATHER 1
+#define PRIO_OUT 3
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+struct GatherArgs {
+  int chunk0, nchunks, model;
+  double lambda, mu;
+  const ElemTable *tab;
+  const unsigned char *maps;
+  GatherLayout lay;
+  const double *X0, *x;          // [N][4]
+  double *K, *f;
+  int *bad;
+  unsigned long long *stamps;    // diagnostic build only: [chunk][8] s_memtime deltas
+  int ablate;                    // diagnostic build only: timing experiments (results meaningless)
+};
+#ifdef FEAHIP_DEBUG
+#define G_ABL(bit) (A.ablate & (bit))
+#else
+#define G_ABL(bit) 0
+#endif
+
+#ifdef FEAHIP_DEBUG
+#define G_STAMP(i) do { if (A.stamps) st[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define G_STAMP(i) do { } while (0)
+#endif
+
+#define G_RS 0
+#define G_RD 20
+#define G_VF 40
+
+#define GREC 26                  // doubles per element record (stiffness): g[4][3], t[4][3], vl, vm
+#define GREC_F 12                // residual only: s[4][3] = vol sigma g
+
+// Record layout (13 pieces of 16 bytes; every read of a record is one aligned ds_read_b128, and which LDS bank
+// slot a piece falls into is decided by the record's slot mod 16 -- gather.cpp places the elements accordingly):
+//   pieces 0-3 P_k = (g_k.x, g_k.y)   4-7 Q_k = (t_k.x, t_k.y)   8-11 Z_k = (g_k.z, t_k.z)   12 (vl, vm)
+// residual-only record (6 pieces): 0-3 (s_k.x, s_k.y), 4-5 (s_0.z .. s_3.z), s = vol sigma g
+//
+// one contribution (element slot, local row node la, local column node lb) to the thread's block
+// (an empty slot of the list points at an all-zero record: no branch)
+struct GRead { double2 pa, za, pb, qb, zb, vv; };
+__device__ __forceinline__ GRead g_fetch(const double *sT, unsigned w)
+{
+  const double2 *T = reinterpret_cast<const double2 *>(sT + (w & 255u) * GREC);
+  const int la = (w >> 8) & 3, lb = (w >> 10) & 3;
+  GRead r;
+  r.pa = T[la]; r.za = T[8 + la]; r.pb = T[lb]; r.qb = T[4 + lb]; r.zb = T[8 + lb]; r.vv = T[12];
+  return r;
+}
+__device__ __forceinline__ void g_apply(const GRead &r, double (&acc)[9])
+{
+  const double ga0 = r.pa.x, ga1 = r.pa.y, ga2 = r.za.x;
+  const double gb0 = r.pb.x, gb1 = r.pb.y, gb2 = r.zb.x;
+  const double tb0 = r.qb.x, tb1 = r.qb.y, tb2 = r.zb.y;
+  const double vl = r.vv.x, vm = r.vv.y;
+  const double h0 = vl * gb0, h1 = vl * gb1, h2 = vl * gb2;
+  const double m0 = vm * gb0, m1 = vm * gb1, m2 = vm * gb2;
+  const double d = ga0 * tb0 + ga1 * tb1 + ga2 * tb2;
+  acc[0] += d; acc[4] += d; acc[8] += d;
+  acc[0] = fma(ga0, h0, fma(ga0, m0, acc[0])); acc[1] = fma(ga0, h1, fma(ga1, m0, acc[1])); acc[2] = fma(ga0, h2, fma(ga2, m0, acc[2]));
+  acc[3] = fma(ga1, h0, fma(ga0, m1, acc[3])); acc[4] = fma(ga1, h1, fma(ga1, m1, acc[4])); acc[5] = fma(ga1, h2, fma(ga2, m1, acc[5]));
+  acc[6] = fma(ga2, h0, fma(ga0, m2, acc[6])); acc[7] = fma(ga2, h1, fma(ga1, m2, acc[7])); acc[8] = fma(ga2, h2, fma(ga2, m2, acc[8]));
+}
+__device__ __forceinline__ void g_consume(const double *sT, unsigned w, double (&acc)[9])
+{
+  g_apply(g_fetch(sT, w), acc);
+}
+__device__ __forceinline__ void g_apply_cheap(const GRead &r, double (&acc)[9])
+{
+  acc[0] += r.pa.x; acc[1] += r.za.x; acc[2] += r.pb.x; acc[3] += r.qb.x; acc[4] += r.zb.x; acc[5] += r.vv.x;
+}
+__device__ __forceinline__ GRead g_fetch_cheap(const double *sT, unsigned w)
+{
+  GRead r; const double v = (double)w;
+  r.pa = make_double2(v, v); r.za = r.pa; r.pb = r.pa; r.qb = r.pa; r.zb = r.pa; r.vv = r.pa;
+  return r;
+}
+
+// one visit (element slot, local node la) to a row's diagonal block: K_aa^e = (vl + vm) g_a (x) g_a + (g_a . t_a) I,
+// symmetric: a = { 00, 01, 02, 11, 12, 22 }
+template <bool DOF>
+__device__ __forceinline__ void g_consume_diag(const double *sT, unsigned w, double (&a)[6], double (&fa)[3])
+{
+  const double2 *T = reinterpret_cast<const double2 *>(sT + (w & 255u) * GREC);
+  const int la = (w >> 8) & 3;
+  const double2 pa = T[la], qa = T[4 + la], za = T[8 + la], vv = T[12];
+  const double s = vv.x + vv.y;
+  const double d = pa.x * qa.x + pa.y * qa.y + za.x * za.y;
+  const double h0 = s * pa.x, h1 = s * pa.y, h2 = s * za.x;
+  a[0] += fma(h0, pa.x, d); a[1] = fma(h0, pa.y, a[1]); a[2] = fma(h0, za.x, a[2]);
+  a[3] += fma(h1, pa.y, d); a[4] = fma(h1, za.x, a[4]); a[5] += fma(h2, za.x, d);
+  if (DOF) {
+    // the same visits carry the row's residual: -vol sigma g_a = -(t_a - vm g_a), with the product rounded exactly
+    // as it was when t_a was formed (no fused multiply-add on either side): a stress-free state gives f = 0 to the bit
+    fa[0] -= __dsub_rn(qa.x, __dmul_rn(vv.y, pa.x)); fa[1] -= __dsub_rn(qa.y, __dmul_rn(vv.y, pa.y)); fa[2] -= __dsub_rn(za.y, __dmul_rn(vv.y, za.x));
+  }
+}
+
+// The same sums with the LDS reads of ALL the listed contributions issued before the first is summed: a wave that
+// reads one contribution, waits, and sums it pays the LDS latency once per contribution (measured in the producer /
+// consumer kernel, two waves per SIMD: 350-600 cycles per contribution); issued together the reads queue in the LDS
+// pipe and return while the earlier ones are summed.  D = list words (two contributions each) held in registers.
+template <int K0, int D>
+__device__ __forceinline__ void g_gather_batch(const double *sT, const unsigned (&cw)[FEA_G_REGW], double (&acc)[9])
+{
+  GRead r[2 * D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) { r[2 * k] = g_fetch(sT, cw[K0 + k] & 0xFFFFu); r[2 * k + 1] = g_fetch(sT, cw[K0 + k] >> 16); }
+#pragma unroll
+  for (int k = 0; k < 2 * D; ++k) g_apply(r[k], acc);
+}
+
+struct GDiagRead { double2 pa, qa, za, vv; };
+__device__ __forceinline__ GDiagRead g_fetch_diag(const double *sT, unsigned w)
+{
+  const double2 *T = reinterpret_cast<const double2 *>(sT + (w & 255u) * GREC);
+  const int la = (w >> 8) & 3;
+  GDiagRead r;
+  r.pa = T[la]; r.qa = T[4 + la]; r.za = T[8 + la]; r.vv = T[12];
+  return r;
+}
+template <bool DOF>
+__device__ __forceinline__ void g_apply_diag(const GDiagRead &r, double (&a)[6], double (&fa)[3])
+{
+  const double2 pa = r.pa, qa = r.qa, za = r.za, vv = r.vv;
+  const double s = vv.x + vv.y;
+  const double d = pa.x * qa.x + pa.y * qa.y + za.x * za.y;
+  const double h0 = s * pa.x, h1 = s * pa.y, h2 = s * za.x;
+  a[0] += fma(h0, pa.x, d); a[1] = fma(h0, pa.y, a[1]); a[2] = fma(h0, za.x, a[2]);
+  a[3] += fma(h1, pa.y, d); a[4] = fma(h1, za.x, a[4]); a[5] += fma(h2, za.x, d);
+  if (DOF) {
+    fa[0] -= __dsub_rn(qa.x, __dmul_rn(vv.y, pa.x)); fa[1] -= __dsub_rn(qa.y, __dmul_rn(vv.y, pa.y)); fa[2] -= __dsub_rn(za.y, __dmul_rn(vv.y, za.x));
+  }
+}
+// list words [K0, K0 + D) of a diagonal lane: 2 D visits read, then summed
+template <int K0, int D, bool DOF>
+__device__ __forceinline__ void g_diag_batch(const double *sT, const unsigned (&cw)[FEA_G_REGW], double (&a)[6], double (&fa)[3])
+{
+  GDiagRead r[2 * D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) { r[2 * k] = g_fetch_diag(sT, cw[K0 + k] & 0xFFFFu); r[2 * k + 1] = g_fetch_diag(sT, cw[K0 + k] >> 16); }
+#pragma unroll
+  for (int k = 0; k < 2 * D; ++k) g_apply_diag<DOF>(r[k], a, fa);
+}
+
+// residual contribution of one (element, local node) visit: -vol sigma g_a (fea_solver.c:1096-1109)
+template <bool DOK>
+__device__ __forceinline__ void g_visit(const double *sT, unsigned w, double (&fa)[3])
+{
+  const int la = (w >> 8) & 3;
+  if (DOK) {
+    const double2 *T = reinterpret_cast<const double2 *>(sT + (w & 255u) * GREC);
+    const double2 pa = T[la], qa = T[4 + la], za = T[8 + la];
+    const double vm = T[12].y;
+    fa[0] -= qa.x - vm * pa.x; fa[1] -= qa.y - vm * pa.y; fa[2] -= za.y - vm * za.x;
+  } else {
+    const double *T = sT + (w & 255u) * GREC_F;
+    const double2 pa = *reinterpret_cast<const double2 *>(T + 2 * la);
+    fa[0] -= pa.x; fa[1] -= pa.y; fa[2] -= T[8 + la];
+  }
+}
+
+// logical record R = { g[4][3], t[4][3], vl, vm } (or { s[4][3] }) -> the piece layout above
+// two doubles of a record -> LDS with one ds_write2_b64: the instruction takes its two operands from ANY two register
+// pairs, whereas the ds_write_b128 the compiler forms out of adjacent stores needs four consecutive registers and cost
+// 47 v_mov_b64 per record to pack them.  Inline asm: the compiler does not see these stores, so the caller waits for
+// them itself (G_LDS_DRAIN) before the barrier.
+#define G_W2(addr, a, b, o) asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(addr), "v"(a), "v"(b), "n"(o), "n"((o) + 1) : "memory")
+#define G_LDS_DRAIN() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <bool DOK>
+__device__ __forceinline__ void g_store_record(double *dst, const double *R)
+{
+  const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)dst;
+  G_W2(a, R[0], R[1], 0); G_W2(a, R[3], R[4], 2); G_W2(a, R[6], R[7], 4); G_W2(a, R[9], R[10], 6);
+  if (DOK) {
+    G_W2(a, R[12], R[13], 8); G_W2(a, R[15], R[16], 10); G_W2(a, R[18], R[19], 12); G_W2(a, R[21], R[22], 14);
+    G_W2(a, R[2], R[14], 16); G_W2(a, R[5], R[17], 18); G_W2(a, R[8], R[20], 20); G_W2(a, R[11], R[23], 22);
+    G_W2(a, R[24], R[25], 24);
+  } else {
+    G_W2(a, R[2], R[5], 8); G_W2(a, R[8], R[11], 10);
+  }
+}
+
+// Element record of a constant-strain tetrahedron straight from its node coordinates, in the fewest operations:
+//   J = [x_k - x_0], g_k = rows of adj(J)/det J (k = 1..3), g_0 = -(g_1 + g_2 + g_3)      fea_solver.c:690-718
+//   F^-1 = sum_k (X_k - X_0) (x) g_k                                                     fea_solver.c:1141-1151
+//   Neo-Hookean: B = F F' = (F^-T F^-1)^-1 by the adjugate of the symmetric C = Fi'Fi, J = 1/det Fi:
+//     vol sigma = vol mu J adj(C) - vol (mu - lambda ln J)/J I,  l1 = lambda/J, m1 = (mu - lambda ln J)/J
+//                                                                                        fea_model.c:79-107,129-148
+//   t_k = vol (m1 g_k + sigma g_k)
+// R = { g[4][3], t[4][3], vol l1, vol m1 } (DOK) or { vol sigma g [4][3] } (residual only).
+// Returns det J (its sign and zero test are the caller's business).
+template <bool DOK>
+__device__ __forceinline__ double lintet_record_nh(const double (&x)[4][3], const double (&X)[4][3], double w,
+                                                   double lambda, double mu, double *R)
+{
+  double J[3][3], D[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { J[i][j] = x[i + 1][j] - x[0][j]; D[i][j] = X[i + 1][j] - X[0][j]; }
+  // cofactors: c[k][i] = d detJ / d J[k][i]  ->  g_{k+1}[i] = c[k][i] / det... with J[k][.] = x_{k+1} - x_0 the
+  // inverse Ji[i][k] = cof(J)[k][i]/det, and g_{k+1}[i] = Ji[i][k]
+  double c[3][3];
+  c[0][0] = J[1][1] * J[2][2] - J[1][2] * J[2][1]; c[0][1] = J[1][2] * J[2][0] - J[1][0] * J[2][2]; c[0][2] = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+  c[1][0] = J[0][2] * J[2][1] - J[0][1] * J[2][2]; c[1][1] = J[0][0] * J[2][2] - J[0][2] * J[2][0]; c[1][2] = J[0][1] * J[2][0] - J[0][0] * J[2][1];
+  c[2][0] = J[0][1] * J[1][2] - J[0][2] * J[1][1]; c[2][1] = J[0][2] * J[1][0] - J[0][0] * J[1][2]; c[2][2] = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+  const double detJ = J[0][0] * c[0][0] + J[0][1] * c[0][1] + J[0][2] * c[0][2];
+  const double id = fd_rcp(detJ);
+  double g[4][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g[k + 1][i] = c[k][i] * id;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) g[0][i] = -((g[1][i] + g[2][i]) + g[3][i]);
+  // Fi[i][j] = sum_k g_{k+1}[j] D[k][i]
+  double Fi[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Fi[i][j] = g[1][j] * D[0][i] + g[2][j] * D[1][i] + g[3][j] * D[2][i];
+  const double detFi = fd_det3(Fi);
+  const double Jd = fd_rcp(detFi);                    // J = det F
+  const double lnJ = -fd_log(detFi);
+  double c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    c00 += Fi[i][0] * Fi[i][0]; c01 += Fi[i][0] * Fi[i][1]; c02 += Fi[i][0] * Fi[i][2];
+    c11 += Fi[i][1] * Fi[i][1]; c12 += Fi[i][1] * Fi[i][2]; c22 += Fi[i][2] * Fi[i][2];
+  }
+  const double vol = w * fabs(detJ);
+  const double m1 = (mu - lambda * lnJ) * detFi;      // (mu - lambda ln J)/J
+  const double vm = vol * m1;
+  const double mJ = (vol * mu) * Jd;                  // vol mu J
+  double S[3][3];                                     // vol sigma
+  S[0][0] = mJ * (c11 * c22 - c12 * c12) - vm;
+  S[1][1] = mJ * (c00 * c22 - c02 * c02) - vm;
+  S[2][2] = mJ * (c00 * c11 - c01 * c01) - vm;
+  S[0][1] = S[1][0] = mJ * (c02 * c12 - c01 * c22);
+  S[0][2] = S[2][0] = mJ * (c01 * c12 - c02 * c11);
+  S[1][2] = S[2][1] = mJ * (c01 * c02 - c00 * c12);
+  if (DOK) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) R[b * 3 + i] = g[b][i];
+    // t_b = round(vm g_b) + vol sigma g_b, every node alike and without fused multiply-add, so that the residual
+    // -(t_a - round(vm g_a)) of a stress-free state is zero to the bit (g_consume_diag)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        R[12 + b * 3 + i] = __dadd_rn(__dmul_rn(vm, g[b][i]), S[i][0] * g[b][0] + S[i][1] * g[b][1] + S[i][2] * g[b][2]);
+    R[24] = (vol * lambda) * detFi;                   // vol lambda/J
+    R[25] = vm;
+  } else {
+#pragma unroll
+    for (int b = 1; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) R[b * 3 + i] = S[i][0] * g[b][0] + S[i][1] * g[b][1] + S[i][2] * g[b][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) R[i] = -((R[3 + i] + R[6 + i]) + R[9 + i]);
+  }
+  return detJ;
+}
+
+// any model through the general state of fem_device.h (A5)
+template <bool DOK>
+__device__ __forceinline__ double lintet_record_any(const double (&xe)[4][3], const double (&Xe)[4][3], const ElemTable *tab,
+                                                    int model, double lambda, double mu, double *R)
+{
+  GPState<4> s;
+  gp_state<4, true, false>(xe, Xe, tab, 0, model, lambda, mu, s);
+  const double vm = s.vol * s.m1;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double sg = s.vol * (s.sig[i][0] * s.g[b][0] + s.sig[i][1] * s.g[b][1] + s.sig[i][2] * s.g[b][2]);
+      if (DOK) { R[b * 3 + i] = s.g[b][i]; R[12 + b * 3 + i] = __dadd_rn(__dmul_rn(vm, s.g[b][i]), sg); }
+      else R[b * 3 + i] = sg;
+    }
+  if (DOK) { R[24] = s.vol * s.l1; R[25] = vm; }
+  return s.detJ;
+}
+
+// workgroup barrier that orders LDS only: __syncthreads() would also drain every global load and store in flight
+// (s_waitcnt vmcnt(0)), i.e. the prefetches of the next chunk and the row stores of the previous one
+#define G_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
+
+typedef int g_v8i __attribute__((ext_vector_type(8)));
+typedef int g_v4i __attribute__((ext_vector_type(4)));
+
+// what a thread holds of one chunk's map record
+struct GMaps {
+  unsigned eids, tpos, cw[FEA_G_REGW], vw[2];
+  int kd, vb, ve;
+};
+
+#define G_TASK_THREADS 192           // block and residual threads: waves 0-2; wave 3 sums the diagonal blocks
+
+template <bool DOK, bool DOF>
+__device__ __forceinline__ void g_load_maps(const GatherLayout &lay, const unsigned char *rec, int t, GMaps &m)
+{
+  // Loads from inside the record (always in bounds), masked by what the LARGEST chunk of the mesh needs (known
+  // without the header of this chunk, so none of them waits for it); a thread never uses a word it does not own.
+  const unsigned short *rows = reinterpret_cast<const unsigned short *>(rec + lay.o_rows);
+  m.eids = 0xFFFFFFFFu; m.tpos = 0; m.kd = m.vb = m.ve = 0;
+#pragma unroll
+  for (int k = 0; k < FEA_G_REGW; ++k) m.cw[k] = 0;
+  m.vw[0] = m.vw[1] = 0;
+  if (t < lay.max_elems) m.eids = reinterpret_cast<const unsigned *>(rec + lay.o_elems)[t];
+  if (DOK && t < ((lay.max_tasks + 63) & ~63)) {
+    m.tpos = reinterpret_cast<const unsigned *>(rec + lay.o_bpos)[t];
+#pragma unroll
+    for (int k = 0; k < FEA_G_REGW; ++k)
+      if (k < lay.max_depth) m.cw[k] = reinterpret_cast<const unsigned *>(rec + lay.o_clist)[k * FEA_G_THREADS + t];
+  }
+  if (DOK && t >= G_TASK_THREADS) {                   // wave 3: four lanes per row, the visits of its diagonal block
+    const int l = t - G_TASK_THREADS;
+    m.kd = rows[G_RD + (l >> 2)];
+#pragma unroll
+    for (int k = 0; k < FEA_G_REGW; ++k)
+      if (k < lay.max_ddepth) m.cw[k] = reinterpret_cast<const unsigned *>(rec + lay.o_dlist)[k * 64 + l];
+  }
+  if (!DOK && t < ((lay.max_vthr + 63) & ~63)) {
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+      if (v < lay.max_vdepth) m.vw[v] = reinterpret_cast<const unsigned short *>(rec + lay.o_vlist)[v * FEA_G_THREADS + t];
+  }
+  if (!DOK) {
+    const int fr = min(t / 3, FEA_G_MAX_ROWS - 1);
+    m.vb = rows[G_VF + fr]; m.ve = rows[G_VF + fr + 1];
+  }
+}
+

@@ -312,9 +312,17 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
       // GATHER where the chunks of consecutive rows are compact enough that an element is evaluated at most ~2.5
       // times (locality numberings: bricks, space-filling curves); the staged visits otherwise (measured on the
       // 10M-tet block: 0.97 ms against 1.00 with bricks of 4x2x2 nodes, 1.24 against 1.00 with lexicographic ids)
-      { const int rc = ensure_gather(c); if (rc) return rc; }
-      if (c->have_gather && c->gather_evals_per_element <= 2.5) strat = FEAHIP_ASM_GATHER;
+      const bool declined = c->gather_declined_row0 == c->row0 && c->gather_declined_row1 == c->row1;
+      if (!declined) { const int rc = ensure_gather(c); if (rc) return rc; }
+      if (!declined && c->have_gather && c->gather_evals_per_element <= 2.5) strat = FEAHIP_ASM_GATHER;
       else {
+        if (!declined && c->have_gather) {
+          // the maps were built to learn what the chunks cost; AUTO does not run them: they do not stay resident
+          // (84 B per element), and the sizes reported are those of the kernel that runs
+          (void)hipFree(c->d_gmaps); c->d_gmaps = nullptr;
+          c->have_gather = false; c->ngchunks = 0; c->gather_row0 = c->gather_row1 = -1; c->gather_bytes = 0;
+          c->gather_declined_row0 = c->row0; c->gather_declined_row1 = c->row1;
+        }
         { const int rc = ensure_visits(c); if (rc) return rc; }
         if (c->have_visits) strat = FEAHIP_ASM_STAGED;
       }
@@ -331,8 +339,9 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
       strat = (c->have_quad && doK) ? FEAHIP_ASM_SHARED : (rowowner_ok ? FEAHIP_ASM_ROWOWNER : FEAHIP_ASM_ATOMIC);
   }
   if (strat == FEAHIP_ASM_SHARED) { const int rc = ensure_quad(c); if (rc) return rc; }
-  c->last_strategy = strat;
   if (strat == FEAHIP_ASM_SHARED && !doK && c->have_quad) strat = rowowner_ok ? FEAHIP_ASM_ROWOWNER : FEAHIP_ASM_ATOMIC;   // residual alone: visit kernel
+  if (strat == FEAHIP_ASM_PATCH && !doK) strat = FEAHIP_ASM_ROWOWNER;                                                       // residual alone: visit kernel
+  c->last_strategy = strat;                          // the kernel that runs, after the residual-only fallbacks
   if (strat == FEAHIP_ASM_SHARED) {
     if (!c->have_quad) {
       c->err = "shared-state assembly needs 10-node elements whose chunks fit the LDS tiles";
@@ -377,7 +386,6 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
     if (doK) FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));
     return launch_assemble_visit(c, doK, doF, strat == FEAHIP_ASM_PIPELINED);
   }
-  if (strat == FEAHIP_ASM_PATCH && !doK) strat = FEAHIP_ASM_ROWOWNER;   // residual alone: visit kernel
   if (strat == FEAHIP_ASM_PATCH) {
     { const int rc = ensure_patches(c); if (rc) return rc; }
     if (!c->have_patches) {

@@ -439,13 +439,17 @@ void k_assemble_gather10(G10Args A, int run_len)
 int ensure_gather10(feahip_ctx *c)
 {
   if (c->have_gather && c->gather10_lay && c->gather_row0 == c->row0 && c->gather_row1 == c->row1) return FEAHIP_OK;
-  if (c->gather_failed || !c->h_pat || c->h_conn.empty() || (c->npe != 10 && c->npe != 8) || c->G > T_GMAX) return FEAHIP_OK;
-  HostGather10 hg;
-  build_host_gather10(c->N, c->E, c->npe, c->h_conn.data(), *c->h_pat, c->row0, c->row1, hg);
-  if (!hg.ok) { c->gather_failed = true; return FEAHIP_OK; }
+  if (!c->h_pat || c->h_conn.empty() || (c->npe != 10 && c->npe != 8) || c->G > T_GMAX) return FEAHIP_OK;
+  // a new row range (re-shard): the old maps describe rows K no longer holds (release_k re-allocates the window), so
+  // they go before anything else can launch them -- also when the new range is known not to fit, or turns out not to
   for (void *p : {(void *)c->d_gmaps, (void *)c->d_g10_elist, (void *)c->d_g10_state})
     if (p) (void)hipFree(p);
   c->d_gmaps = nullptr; c->d_g10_elist = nullptr; c->d_g10_state = nullptr;
+  c->have_gather = false; c->ngchunks = 0; c->g10_nloc = 0; c->gather_row0 = c->gather_row1 = -1;
+  if (c->gather_failed && c->gather_fail_row0 == c->row0 && c->gather_fail_row1 == c->row1) return FEAHIP_OK;
+  HostGather10 hg;
+  build_host_gather10(c->N, c->E, c->npe, c->h_conn.data(), *c->h_pat, c->row0, c->row1, hg);
+  if (!hg.ok) { c->gather_failed = true; c->gather_fail_row0 = c->row0; c->gather_fail_row1 = c->row1; return FEAHIP_OK; }   // this row range only: another shard of the same context may fit
   c->g10_nloc = (int)hg.elist.size();
   const size_t state_bytes = sizeof(double) * T_HDR * (size_t)c->G * (size_t)std::max(c->g10_nloc, 1);
   FEA_HIP_CHECK(c, hipMalloc((void **)&c->d_gmaps, hg.blob.size() ? hg.blob.size() : 1));
@@ -510,13 +514,9 @@ int launch_assemble_gather10(feahip_ctx *c, bool doK, bool doF)
                     k_assemble_gather10<N_, true, true, true>, k_assemble_gather10<N_, false, true, false>, k_assemble_gather10<N_, false, true, true>
   static const g10_fn fns[12] = {G10_ROW(10), G10_ROW(8)};
 #undef G10_ROW
-  if (lds > 64 * 1024) {
-    static bool raised[12] = {false, false, false, false, false, false, false, false, false, false, false, false};
-    if (!raised[variant]) {
-      FEA_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(fns[variant]), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      raised[variant] = true;
-    }
-  }
+  // on every launch: the attribute belongs to the current device and to the size asked for (another device of an
+  // in-process group, or a later context with a longer Gauss rule, must not inherit the first caller's value)
+  FEA_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(fns[variant]), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL(fns[variant], grid, blk, lds, c->stream, A, run_len);
   FEA_HIP_CHECK(c, hipGetLastError());
 #ifdef FEAHIP_DEBUG

@@ -21,6 +21,14 @@ __device__ __forceinline__ double wave_sum(double v)
   return v;
 }
 
+// the same sum in every lane (butterfly: a fixed order as well)
+__device__ __forceinline__ double wave_sum_all(double v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
 // sum over the 256 threads of a block; result valid in thread 0
 __device__ __forceinline__ double block_sum(double v, double *scratch /*[4]*/)
 {
@@ -184,6 +192,27 @@ __device__ __forceinline__ void spmv_body(int chunk0, int nchunks, const int *ch
   for (int ch = chunk0 + blockIdx.x * FEA_WAVES_PER_WG + wave; ch < chunk0 + nchunks; ch += gridDim.x * FEA_WAVES_PER_WG) {
     const int r0 = chunk[ch], r1 = chunk[ch + 1];
     const int b0 = rowptr[r0], nb = rowptr[r1] - b0;
+    if (nb > FEA_CHUNK_BLOCKS) {
+      // a row with more blocks than the tile: pattern.cpp / amg_setup.cpp give it a chunk of its own.  The lanes
+      // stride over its blocks and their partial products meet in a butterfly: no tile, any length, fixed order
+      // (the reference's solvers have no row-length limit either, fea_solver.c:300-321)
+      double a0 = 0, a1 = 0, a2 = 0;
+      for (int k = lane; k < nb; k += 64) {
+        const int col = colidx[b0 + k];
+        const TK *vp = K + (size_t)(b0 + k) * 9;
+        const double x0 = x[(size_t)col * 3], x1 = x[(size_t)col * 3 + 1], x2 = x[(size_t)col * 3 + 2];
+        a0 += (double)vp[0] * x0 + (double)vp[1] * x1 + (double)vp[2] * x2;
+        a1 += (double)vp[3] * x0 + (double)vp[4] * x1 + (double)vp[5] * x2;
+        a2 += (double)vp[6] * x0 + (double)vp[7] * x1 + (double)vp[8] * x2;
+      }
+      a0 = wave_sum_all(a0); a1 = wave_sum_all(a1); a2 = wave_sum_all(a2);
+      if (lane < 3) {
+        const double acc = lane == 0 ? a0 : lane == 1 ? a1 : a2;
+        y[(size_t)r0 * 3 + lane] = acc;
+        if (dotwith) dsum += acc * dotwith[(size_t)r0 * 3 + lane];
+      }
+      continue;
+    }
     double v[2][9], xv[2][3];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -254,6 +283,25 @@ void k_spmv_jacobi(int nchunks, const int *chunk, const int *rowptr, const int *
   for (int ch = blockIdx.x * FEA_WAVES_PER_WG + wave; ch < nchunks; ch += gridDim.x * FEA_WAVES_PER_WG) {
     const int r0 = chunk[ch], r1 = chunk[ch + 1];
     const int b0 = rowptr[r0], nb = rowptr[r1] - b0;
+    if (nb > FEA_CHUNK_BLOCKS) {                               // one long row in a chunk of its own: see spmv_body
+      double a0 = 0, a1 = 0, a2 = 0;
+      for (int k = lane; k < nb; k += 64) {
+        const int col = colidx[b0 + k];
+        const TK *vp = K + (size_t)(b0 + k) * 9;
+        const double x0 = xin[(size_t)col * 3], x1 = xin[(size_t)col * 3 + 1], x2 = xin[(size_t)col * 3 + 2];
+        a0 += (double)vp[0] * x0 + (double)vp[1] * x1 + (double)vp[2] * x2;
+        a1 += (double)vp[3] * x0 + (double)vp[4] * x1 + (double)vp[5] * x2;
+        a2 += (double)vp[6] * x0 + (double)vp[7] * x1 + (double)vp[8] * x2;
+      }
+      a0 = wave_sum_all(a0); a1 = wave_sum_all(a1); a2 = wave_sum_all(a2);
+      if (lane < 3) {
+        const double *rr = r + (size_t)r0 * 3;
+        const double t0 = rr[0] - a0, t1 = rr[1] - a1, t2 = rr[2] - a2;
+        const double *m = minv + (size_t)r0 * 9 + 3 * lane;
+        xout[(size_t)r0 * 3 + lane] = xin[(size_t)r0 * 3 + lane] + omega * (m[0] * t0 + m[1] * t1 + m[2] * t2);
+      }
+      continue;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int k = lane + 64 * h;
@@ -301,20 +349,8 @@ static int spmv_grid(const feahip_ctx *c)
   return g < FEA_RED_BLOCKS ? (g > 0 ? g : 1) : FEA_RED_BLOCKS;
 }
 
-// k_spmv / k_spmv_jacobi give each lane blocks k and k+64 of a chunk's <= 128-block LDS tile; pattern.cpp puts a row
-// with more blocks than that into a chunk of its own, which these kernels cannot walk (assembly falls back to the
-// atomic path for such meshes, the multigrid refuses them): refuse instead of returning a wrong product.
-static int spmv_supported(feahip_ctx *c)
-{
-  if (c->max_rowlen <= FEA_CHUNK_BLOCKS) return FEAHIP_OK;
-  c->err = "the SpMV / PCG kernels need block rows of at most " + std::to_string(FEA_CHUNK_BLOCKS) +
-           " blocks (a node of this mesh has " + std::to_string(c->max_rowlen) + " neighbours)";
-  return FEAHIP_EINVAL;
-}
-
 int launch_spmv(feahip_ctx *c, const double *d_xv, double *d_yv)
 {
-  { const int rc = spmv_supported(c); if (rc) return rc; }
   hipLaunchKernelGGL(k_spmv, dim3(spmv_grid(c)), dim3(256), 0, c->stream, c->chunk0, c->nchunks_local, c->d_chunk,
                      c->d_rowptr, c->d_colidx, c->d_K, d_xv, d_yv, (const double *)nullptr,
                      (double *)nullptr, (const int *)nullptr);
@@ -702,7 +738,6 @@ int dist_solve_pcg(std::vector<feahip_ctx *> &R, int type, double tol, int max_i
 {
   Transport *T = R[0]->tr;
   feahip_ctx *c0 = R[0];
-  for (feahip_ctx *c : R) { const int rc = spmv_supported(c); if (rc) { c0->err = c->err; return rc; } }
   const int mode = (type == FEAHIP_CG) ? 0 : 1;
   if (type == FEAHIP_CHOLESKY) { tol = 1e-16; if (max_iter < 100000) max_iter = 100000; }
   int rc = enq_cg_start(R, T, mode, tol);
@@ -811,8 +846,7 @@ int time_pcg_iteration(feahip_ctx *c, int warmup, int iters, double *avg_ms)
 {
   std::vector<feahip_ctx *> R(1, c);
   Transport *T = c->tr;
-  int rc = spmv_supported(c);
-  if (rc) return rc;
+  int rc;
   rc = enq_cg_start(R, T, 1, 0.0);
   if (rc) return rc;
   FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));

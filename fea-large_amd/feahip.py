@@ -74,6 +74,8 @@ ABI = {
     "feahip_sizes": [C.c_void_p, C.POINTER(C.c_longlong)],
     "feahip_host_assembly_digest": [C.c_int, C.c_int, C.c_int, _ip, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), _ip],
     "feahip_assembly_in_use": [C.c_void_p, _ip],
+    "feahip_node_numbering": [C.c_void_p, _ip],
+    "feahip_host_numbering": [C.c_int, C.c_int, C.c_int, _ip, _dp, _ip],
 }
 
 _lib = None
@@ -433,9 +435,26 @@ class FeaSolver:
         self._chk(self._lib.feahip_set_row_shard(self._ctx, rank, nranks))
 
     def owned_rows(self):
+        """[row0, row1) in LIBRARY node ids (see node_numbering / owned_nodes)."""
         a, b = C.c_int(0), C.c_int(0)
         self._chk(self._lib.feahip_owned_rows(self._ctx, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def node_numbering(self):
+        """library id of every caller's node (the identity when the library kept the caller's numbering)."""
+        out = np.empty(self.N, dtype=np.int32)
+        self._chk(self._lib.feahip_node_numbering(self._ctx, _i(out)))
+        return out
+
+    def owned_nodes(self):
+        """the caller's ids of the nodes this rank owns, ascending."""
+        r0, r1 = self.owned_rows()
+        lib = self.node_numbering()
+        return np.nonzero((lib >= r0) & (lib < r1))[0]
+
+    def owned_dofs(self):
+        """the caller's dof indices (node * 3 + axis) of the nodes this rank owns, ascending."""
+        return (3 * self.owned_nodes()[:, None] + np.arange(3)[None, :]).ravel()
 
     def comm_init(self, rank, nranks, unique_id):
         """unique_id: the 128 bytes rank 0 obtained from comm_unique_id()."""
@@ -461,6 +480,17 @@ class FeaSolver:
         v = C.c_int(0)
         self._chk(self._lib.feahip_assembly_in_use(self._ctx, C.byref(v)))
         return v.value
+
+
+def host_numbering(elements, nodes):
+    """(library id of every node, renumbered?) that feahip_create would choose for this mesh; host only."""
+    el = np.ascontiguousarray(elements, dtype=np.int32)
+    x = np.ascontiguousarray(nodes, dtype=np.float64)
+    out = np.empty(len(x), dtype=np.int32)
+    rc = load_library().feahip_host_numbering(len(x), el.shape[0], el.shape[1], _i(el), _d(x), _i(out))
+    if rc < 0:
+        raise FeaHipError(f"feahip_host_numbering failed ({rc})")
+    return out, bool(rc)
 
 
 def host_assembly_digest(elements, n_nodes, rank=0, nranks=1):
@@ -515,7 +545,8 @@ class FeaGroup:
         self._lib = load_library()
         self._arr = (C.c_void_p * n)(*[r._ctx for r in self.ranks])
         self._chk(self._lib.feahip_group_init(self._arr, n))
-        self.rows = [r.owned_rows() for r in self.ranks]
+        self.rows = [r.owned_rows() for r in self.ranks]        # library ids
+        self.nodes = [r.owned_nodes() for r in self.ranks]      # the caller's ids of every rank's nodes
 
     def _chk(self, rc):
         if rc != 0:
@@ -554,11 +585,12 @@ class FeaGroup:
         """Owned rows of a per-node ([N][3]) or per-dof ([3N]) getter, stitched together."""
         parts = self.each(name)
         out = parts[0].copy()
-        for (a, b), p in zip(self.rows, parts):
+        for nd, p in zip(self.nodes, parts):
             if out.ndim == 2:
-                out[a:b] = p[a:b]
+                out[nd] = p[nd]
             else:
-                out[3 * a:3 * b] = p[3 * a:3 * b]
+                d = (3 * nd[:, None] + np.arange(3)[None, :]).ravel()
+                out[d] = p[d]
         return out
 
     def close(self):

@@ -168,10 +168,16 @@ int feahip_solve(feahip_ctx *ctx, int load_increments, int max_newton,
  * broadcasts it by any means (bench.py: torch.distributed), every rank calls
  * feahip_comm_init; after that the ordinary entries above (create_stiffness,
  * apply_prescribed_bc, solve_slae, energy, update_nodes_with_solution, solve)
- * are collective over the ranks.  Every rank holds the whole mesh.          */
+ * are collective over the ranks.  A rank holds the K rows, the modified-Newton
+ * copy, the assembly maps and the multigrid hierarchy of its own slab only;
+ * the mesh arrays handed to feahip_create are the whole mesh on every rank
+ * (DESIGN.md section 6 says what is sharded and what is not).                */
 int feahip_comm_unique_id(void *out, int cap);
 int feahip_comm_init(feahip_ctx *ctx, int rank, int nranks, const void *unique_id);
-/* nodes [row0, row1) are this rank's; getters are authoritative there only  */
+/* nodes with LIBRARY id in [row0, row1) are this rank's; getters are
+ * authoritative there only (feahip_node_numbering maps the caller's node ids
+ * to library ids: a slab of library ids is a slab of the mesh, not a range of
+ * the caller's ids)                                                          */
 int feahip_owned_rows(feahip_ctx *ctx, int *row0, int *row1);
 
 /* In-process group: n contexts of the same mesh (on any devices) driven by one
@@ -188,7 +194,8 @@ int feahip_group_solve(feahip_ctx **ctxs, int n, int load_increments, int max_ne
                        int tol_log_cap, int *its_log, int *steps_done);
 
 /* Host-only (no device): the halo plan of one rank from the element->node
- * map.  First call with null lists fills counts[5] = {npeers, nsend, nrecv,
+ * map, in the numbering it is given (a context plans in library ids: pass
+ * elements translated by feahip_host_numbering to get what it gets).  First call with null lists fills counts[5] = {npeers, nsend, nrecv,
  * row0, row1}; second call fills peers[npeers], send_off/recv_off[npeers+1],
  * send_idx[nsend], recv_idx[nrecv] (node ids, ascending per peer).           */
 int feahip_shard_plan(int n_nodes, int n_elems, int npe, const int *elements, int rank,
@@ -203,6 +210,26 @@ int feahip_shard_plan(int n_nodes, int n_elems, int npe, const int *elements, in
  * unsharded ones (tests/test_host.py).                                      */
 int feahip_host_assembly_digest(int n_nodes, int n_elems, int npe, const int *elements, int rank, int nranks,
                                 unsigned long long *rowhash, int *rows);
+
+/* ---- node numbering ---------------------------------------------------- */
+/* The reference keeps the nodes in deck order (sexp_loader.c:170-215) and its
+ * dof index is node * 3 + axis (fea_solver.c:377-384).  The kernels here own
+ * runs of consecutive block rows, so feahip_create numbers the nodes itself
+ * (compact cells of ~16 nodes, cells in slabs across the longest axis;
+ * csrc/renumber.cpp) and works in that numbering.  Every entry of this header
+ * that takes or returns node-indexed data translates: the caller passes and
+ * receives its OWN node ids and dof indices, bit-exactly -- elements,
+ * prescribed node ids, coordinates, forces, solution, the Yale matrix (rows,
+ * columns, sorted as the caller's ids sort), SpMV vectors.  Only the shard
+ * ranges (feahip_owned_rows, feahip_shard_plan, feahip_host_assembly_digest)
+ * speak of library ids.  library_id_of_node[n_nodes]: library id of the
+ * caller's node a (the identity when the caller's numbering was kept).       */
+int feahip_node_numbering(feahip_ctx *ctx, int *library_id_of_node);
+/* Host-only (no device): the numbering feahip_create would choose for this
+ * mesh; returns 1 when it is a renumbering, 0 when the caller's ids are kept
+ * (the identity is written then), negative on error.                         */
+int feahip_host_numbering(int n_nodes, int n_elems, int npe, const int *elements,
+                          const double *nodes0, int *library_id_of_node);
 
 /* ---- reference-shaped views -------------------------------------------- */
 
@@ -232,9 +259,12 @@ int feahip_spmv(feahip_ctx *ctx, const double *x, double *y);
 
 int feahip_set_assembly(feahip_ctx *ctx, int strategy);
 /* Preconditioner of the PCG_ILU / CHOLESKY solves: 0 = inverse 3x3 diagonal
- * blocks (default), 1 = aggregation multigrid V-cycle (single rank; a sharded
- * context keeps block-Jacobi).  Either way the solve runs to the requested
- * residual, so the solution is the same to that tolerance.                   */
+ * blocks (default), 1 = aggregation multigrid (rigid-body modes of every
+ * aggregate, W-cycle).  In a sharded solve every rank builds the hierarchy of
+ * its own diagonal block and the preconditioner is block-Jacobi over the ranks
+ * with a W-cycle inside each: no communication beyond the CG's own.  Either
+ * way the solve runs to the requested residual, so the solution is the same
+ * to that tolerance.                                                          */
 int feahip_set_preconditioner(feahip_ctx *ctx, int kind);
 /* Line search along every Newton step of feahip_solve / feahip_group_solve:
  * golden-section search, `max_iterations` iterations, for the step length in

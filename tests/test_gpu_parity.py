@@ -11,6 +11,7 @@ import shutil
 
 import numpy as np
 import pytest
+import scipy.sparse as sp
 
 import feahip
 import mesh
@@ -566,7 +567,8 @@ def test_feasolver_hip_command_line(decks_dir, tmp_path):
 def test_node_with_more_neighbours_than_the_spmv_tile():
     """A fan of 140 tetrahedra pairs around one node: its block row has 143 blocks, more than the 128-block LDS
     tile of the SpMV / PCG kernels (and of the row-owner assembly).  Assembly must still be right (AUTO falls back
-    to the atomic scatter), and the product / solve must refuse loudly instead of dropping blocks 128+."""
+    to the atomic scatter), and product and solve walk the long row with the lanes striding over its blocks: the
+    reference's solvers have no row-length limit (fea_solver.c:300-321), so neither has this path."""
     m = 140
     ang = 2 * np.pi * np.arange(m) / m
     ring = np.stack([np.cos(ang), np.sin(ang), np.zeros(m)], axis=1)
@@ -577,8 +579,9 @@ def test_node_with_more_neighbours_than_the_spmv_tile():
         a, b = 1 + i, 1 + (i + 1) % m
         el.append([0, a, b, top])
         el.append([0, b, a, bot])
+    # both apexes clamped, one ring node held in y: no rigid motion left (the rotation about the apex axis would be)
     deck = feahip.Deck(nodes=nodes, elements=np.array(el, dtype=np.int32), ele_type=feahip.TETRAHEDRA4, gauss_nodes_count=1,
-                       presc_node=[top, bot], presc_type=[7, 7], presc_values=np.zeros((2, 3)))
+                       presc_node=[top, bot, 1], presc_type=[7, 7, 2], presc_values=np.zeros((3, 3)))
     x = nodes * np.array([1.02, 0.99, 1.05]) + 1e-3 * np.sin(3 * nodes[:, [1, 2, 0]])
     s, o = make_pair(deck, x)
     o.update_state(); o.create_stiffness(); o.create_residual_forces()
@@ -588,11 +591,16 @@ def test_node_with_more_neighbours_than_the_spmv_tile():
     assert np.array_equal(off, o.offsets()) and np.array_equal(idx, o.indexes())
     assert off[3] - off[0] == 3 * 3 * (m + 3)                  # the centre's three rows: 143 blocks
     assert rel(val, o.values()) < K_TOL and rel(s.forces(), o.forces()) < K_TOL
-    with pytest.raises(feahip.FeaHipError, match="block rows of at most 128"):
-        s.spmv(np.ones(s.ndof))
-    s.apply_prescribed_bc(0.0)
-    with pytest.raises(feahip.FeaHipError, match="block rows of at most 128"):
-        s.solve_slae(feahip.PCG_ILU, 1e-12, 100)
+    K = sp.csr_matrix((val, idx, off), shape=(s.ndof, s.ndof))
+    xs = np.random.default_rng(3).normal(size=s.ndof)
+    assert rel(s.spmv(xs), K @ xs) < 1e-13                     # the 143-block row included
+    s.apply_prescribed_bc(0.0); o.apply_prescribed_bc(0.0)
+    o.solve_slae(feahip.CHOLESKY)
+    for solver in (feahip.PCG_ILU, feahip.CG):
+        it, res = s.solve_slae(solver, 1e-15, 5000)
+        assert res < 1e-13
+        assert rel(s.solution(), o.solution()) < 1e-10
+    assert s.energy() == pytest.approx(o.energy(), rel=1e-10)
     s.close(); o.close()
 
 
@@ -624,7 +632,7 @@ def test_tet10_hub_node_beyond_every_chunk_limit():
         el.append(row)
     nodes = np.array(nodes)
     deck = feahip.Deck(nodes=nodes, elements=np.array(el, dtype=np.int32), ele_type=feahip.TETRAHEDRA10, gauss_nodes_count=5,
-                       presc_node=[top, bot], presc_type=[7, 7], presc_values=np.zeros((2, 3)))
+                       presc_node=[top, bot, 1], presc_type=[7, 7, 2], presc_values=np.zeros((3, 3)))
     x = nodes * np.array([1.02, 0.99, 1.05]) + 1e-3 * np.sin(3 * nodes[:, [1, 2, 0]])
     s, o = make_pair(deck, x)
     o.update_state(); o.create_stiffness(); o.create_residual_forces()
@@ -638,4 +646,14 @@ def test_tet10_hub_node_beyond_every_chunk_limit():
     s.set_assembly(feahip.ASM_GATHER)
     with pytest.raises(feahip.FeaHipError, match="gather assembly"):
         s.create_stiffness_and_residual()
+    # the hub's block row (about 430 blocks: itself, the ring, the apexes and every mid-side node of its 140 elements)
+    # through the product and the solve: displacement increment of the first Newton step against the oracle's direct solve
+    s.set_assembly(feahip.ASM_AUTO)
+    s.create_stiffness_and_residual()
+    assert np.diff(off)[0] // 3 > 128
+    s.apply_prescribed_bc(0.0); o.apply_prescribed_bc(0.0)
+    o.solve_slae(feahip.CHOLESKY)
+    it, res = s.solve_slae(feahip.PCG_ILU, 1e-15, 20000)
+    assert res < 1e-13
+    assert rel(s.solution(), o.solution()) < 1e-10
     s.close(); o.close()

@@ -40,22 +40,25 @@ def test_sharded_assembly_is_the_unsharded_one(n, strategy, quadratic):
     g.each("create_stiffness_and_residual")
     seen = np.zeros(len(deck.nodes), dtype=int)
     kscale, fscale = np.abs(val).max(), np.abs(f).max()
-    for (a, b), r in zip(g.rows, g.ranks):
-        seen[a:b] += 1
+    row_of_value = np.repeat(np.arange(one.ndof), np.diff(off))   # Yale values -> the caller's dof row
+    for nd, r in zip(g.nodes, g.ranks):                           # nd: the caller's ids of the rank's nodes (a slab of the
+        seen[nd] += 1                                             # library's numbering, not a range of the caller's)
+        own_node = np.zeros(len(deck.nodes), dtype=bool); own_node[nd] = True
+        mine = own_node[row_of_value // 3]
+        d = r.owned_dofs()
         _, _, v = r.matrix_yale()
-        lo, hi = off[3 * a], off[3 * b]
         if strategy == feahip.ASM_STAGED:
-            assert np.array_equal(v[lo:hi], val[lo:hi])           # owned rows: same bits
+            assert np.array_equal(v[mine], val[mine])             # owned rows: same bits
         else:
             assert r.assembly_in_use() == feahip.ASM_GATHER
-            assert np.abs(v[lo:hi] - val[lo:hi]).max() < 4e-16 * kscale
-        assert np.all(v[:lo] == 0) and np.all(v[hi:] == 0)        # nothing else written
+            assert np.abs(v[mine] - val[mine]).max() < 4e-16 * kscale
+        assert np.all(v[~mine] == 0)                              # nothing else written
         if quadratic:
-            assert np.abs(r.forces()[3 * a:3 * b] - f[3 * a:3 * b]).max() < 4e-16 * fscale
+            assert np.abs(r.forces()[d] - f[d]).max() < 4e-16 * fscale
             r.create_residual_forces()                            # the residual alone: same kernel without the blocks
-            assert np.abs(r.forces()[3 * a:3 * b] - f[3 * a:3 * b]).max() < 4e-16 * fscale
+            assert np.abs(r.forces()[d] - f[d]).max() < 4e-16 * fscale
         else:
-            assert np.array_equal(r.forces()[3 * a:3 * b], f[3 * a:3 * b])
+            assert np.array_equal(r.forces()[d], f[d])
     assert np.all(seen == 1)
     g.close(); one.close()
 

@@ -1,0 +1,266 @@
+"""The library's own node numbering (fea-large_amd/csrc/renumber.cpp).
+
+The reference keeps the nodes in deck order (sexp_loader.c:170-215) and its dof index is node * 3 + axis
+(fea_solver.c:377-384).  feahip_create numbers the nodes itself -- compact cells, cells in slabs across the longest
+axis -- runs everything in that numbering and translates at the ABI, so the caller keeps its own indexing bit-exactly.
+CPU tests: what the numbering is (host only).  GPU tests: every node-indexed entry of the ABI against the oracle in
+the CALLER's numbering, for a mesh the library renumbers; the timed configuration of bench.py (a lexicographically
+numbered block, which the library turns into bricks of 4 x 2 x 2 nodes) against the oracle, against the staged-visit
+kernel on the caller's own numbering, sharded, and at its full size.
+"""
+import gzip
+import os
+import shutil
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import feahip
+import mesh
+from oracle_binding import OracleSolver
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
+
+
+# ---------------------------------------------------------------------------------------------- host only
+@pytest.mark.parametrize("n", [5, 13])
+def test_lattice_gets_brick_numbering(n):
+    """On a structured block the numbering IS the brick numbering the gather kernels were tuned on: 4 x 2 x 2 nodes
+    for linear tetrahedra, 3 x 4 x 4 half-grid nodes for 10-node ones, 4 x 4 x 4 for 8-node bricks; a deck that
+    already has it is left alone."""
+    lex = mesh.bar_deck(n=n)
+    perm, renumbered = feahip.host_numbering(lex.elements, lex.nodes)
+    assert renumbered
+    assert np.array_equal(perm, mesh.brick_numbering(n + 1, 6 * n + 1, n + 1, (4, 2, 2)))
+    brick = mesh.bar_deck(n=n, brick=(4, 2, 2))
+    perm2, renumbered2 = feahip.host_numbering(brick.elements, brick.nodes)
+    assert not renumbered2 and np.array_equal(perm2, np.arange(len(brick.nodes)))
+    q = mesh.bar_deck(n=4, quadratic=True)
+    pq, _ = feahip.host_numbering(q.elements, q.nodes)
+    assert np.array_equal(pq, mesh.brick_numbering(9, 49, 9, (3, 4, 4)))
+    h = mesh.bar_deck(n=8, hexa=True)
+    ph, _ = feahip.host_numbering(h.elements, h.nodes)
+    assert np.array_equal(ph, mesh.brick_numbering(9, 49, 9, (4, 4, 4)))
+
+
+def test_unstructured_deck_gets_a_permutation_of_compact_cells(decks_dir, tmp_path):
+    """The reference's largest deck (TetGen numbering, 34 070 nodes): a bijection, deterministic, and 48 consecutive
+    library ids are a compact cluster (their bounding box is a small fraction of the bar), which 48 consecutive
+    TetGen ids are not."""
+    p = tmp_path / "brick_fine.sexp"
+    with gzip.open(os.path.join(decks_dir, "brick_fine.sexp.gz"), "rb") as src, open(p, "wb") as dst:
+        shutil.copyfileobj(src, dst)
+    deck = feahip.Deck.load(str(p))
+    perm, renumbered = feahip.host_numbering(deck.elements, deck.nodes)
+    assert renumbered
+    assert np.array_equal(np.sort(perm), np.arange(len(deck.nodes)))
+    perm2, _ = feahip.host_numbering(deck.elements, deck.nodes)
+    assert np.array_equal(perm, perm2)
+    inv = np.argsort(perm)
+
+    def mean_box_volume(order):
+        v = []
+        for k in range(0, len(order) - 48, 48 * 7):
+            pts = deck.nodes[order[k:k + 48]]
+            v.append(np.prod(pts.max(axis=0) - pts.min(axis=0)))
+        return float(np.mean(v))
+
+    assert mean_box_volume(inv) < 0.05 * mean_box_volume(np.arange(len(deck.nodes)))
+    # slabs across the long axis: the y coordinate grows with the library id (cell by cell)
+    y = deck.nodes[inv, 1]
+    assert y[: len(y) // 8].max() < y[-len(y) // 8:].min()
+
+
+def test_shard_ranges_are_slabs_of_the_library_numbering():
+    """What the row shard cuts are ranges of LIBRARY ids: the host-only plan of the mesh as the library numbers it
+    owns contiguous y-slabs of a lexicographically numbered bar."""
+    deck = mesh.bar_deck(dims=(3, 40, 3))
+    perm, _ = feahip.host_numbering(deck.elements, deck.nodes)
+    lib_elements = perm[deck.elements].astype(np.int32)
+    lib_nodes = np.empty_like(deck.nodes); lib_nodes[perm] = deck.nodes
+    import types
+    d = types.SimpleNamespace(elements=lib_elements, nodes=lib_nodes)
+    seen = np.zeros(len(deck.nodes), dtype=int)
+    hi_prev = -np.inf
+    for r in range(4):
+        plan = feahip.shard_plan(d, r, 4)
+        own = np.arange(plan["row0"], plan["row1"])
+        seen[own] += 1
+        yy = lib_nodes[own, 1]
+        assert yy.min() >= hi_prev - 6.0 / 40 * 2.01          # consecutive slabs (cells of two node planes may interleave)
+        hi_prev = yy.max()
+    assert np.all(seen == 1)
+
+
+# ---------------------------------------------------------------------------------------------- on the GPU
+def _lex_pair(dims=(5, 14, 6), **kw):
+    deck = mesh.bar_deck(dims=dims, **kw)                     # lexicographic ids: the library renumbers
+    x = mesh.deformed_state(deck.nodes, k1=1.07)
+    s, o = feahip.FeaSolver(deck), OracleSolver(deck)
+    s.set_nodes(x); o.set_nodes(x)
+    return deck, x, s, o
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", [feahip.MODEL_COMPRESSIBLE_NEOHOOKEAN, feahip.MODEL_A5])
+def test_renumbered_context_speaks_the_callers_numbering(model):
+    """Every node-indexed entry of the ABI on a mesh the library renumbers, against the oracle run on the caller's
+    numbering: pattern bit-exact (offsets, indexes as the caller's ids sort), K / f / SpMV / BC cancellation / the
+    solved displacement increment / moved nodes, and the gather kernel is what ran."""
+    deck, x, s, o = _lex_pair(model=model)
+    lib = s.node_numbering()
+    assert not np.array_equal(lib, np.arange(len(deck.nodes)))          # it IS renumbered
+    assert np.array_equal(lib, feahip.host_numbering(deck.elements, deck.nodes)[0])
+    assert rel(s.nodes(), x) == 0.0                                      # set / get round trip in the caller's order
+    o.update_state(); o.create_stiffness(); o.create_residual_forces()
+    s.create_stiffness_and_residual()
+    assert s.assembly_in_use() == feahip.ASM_GATHER
+    off, idx, val = s.matrix_yale()
+    assert np.array_equal(off, o.offsets()) and np.array_equal(idx, o.indexes())
+    assert rel(val, o.values()) < 1e-12 and rel(s.forces(), o.forces()) < 1e-12
+    s.create_residual_forces()                                          # the residual-only launch of the same kernel family
+    assert rel(s.forces(), o.forces()) < 1e-12
+    K = sp.csr_matrix((o.values(), o.indexes(), o.offsets()), shape=(s.ndof, s.ndof))
+    v = np.random.default_rng(5).normal(size=s.ndof)
+    assert rel(s.spmv(v), K @ v) < 1e-13
+    s.apply_prescribed_bc(0.0); o.apply_prescribed_bc(0.0)
+    _, _, val_bc = s.matrix_yale()
+    cmask = np.zeros(s.ndof, dtype=bool)                                # the caller's constrained dofs (fea_solver.c:1223)
+    for nd, ty in zip(deck.presc_node, deck.presc_type):
+        for j in range(3):
+            if ty & (1 << j):
+                cmask[3 * nd + j] = True
+    rows = np.repeat(np.arange(s.ndof), np.diff(off))
+    cancelled = (cmask[rows] | cmask[idx]) & (rows != idx)
+    assert cancelled.sum() > 0 and np.all(val_bc[cancelled] == 0) and np.all(o.values()[cancelled] == 0)
+    assert np.all(val_bc[(rows == idx) & cmask[rows]] != 0)             # diagonal kept (fea_solver.c:1255)
+    assert rel(val_bc, o.values()) < 1e-12
+    assert rel(s.forces(), o.forces()) < 1e-12
+    it, res = s.solve_slae(feahip.PCG_ILU, 1e-15, 20000)
+    o.solve_slae(feahip.CHOLESKY)
+    assert rel(s.solution(), o.solution()) < 1e-10
+    assert s.energy() == pytest.approx(o.energy(), rel=1e-10)
+    s.update_nodes_with_solution(); o.update_nodes_with_solution()
+    assert rel(s.nodes(), o.nodes()) < 1e-12
+    # a host vector handed in (caller's order) lands on the same nodes
+    u = s.solution()
+    s.set_nodes(x); s.update_nodes_with_solution(u)
+    assert rel(s.nodes(), x + u.reshape(-1, 3)) < 1e-15
+    s.close(); o.close()
+
+
+@pytest.mark.gpu
+def test_bench_configuration_gather_against_staged_visits_on_the_callers_ids(monkeypatch):
+    """The configuration bench.py times, small: a lexicographically numbered TET4 block that the library numbers in
+    bricks of 4 x 2 x 2 nodes and assembles with the gather kernel -- against the SAME mesh in a context that keeps
+    the caller's ids (FEAHIP_RENUMBER=0) and runs the staged visits: K, f and the residual-only launch to rounding,
+    patterns identical; and a brick-numbered deck (left alone) gives the same bits as the renumbered lexicographic one
+    for the values the caller sees."""
+    dims = (9, 27, 10)
+    deck = mesh.bar_deck(dims=dims)
+    x = mesh.deformed_state(deck.nodes)
+    s = feahip.FeaSolver(deck); s.set_nodes(x); s.create_stiffness_and_residual()
+    assert s.assembly_in_use() == feahip.ASM_GATHER
+    off, idx, val = s.matrix_yale(); f = s.forces()
+    s.create_residual_forces(); f_only = s.forces()
+    monkeypatch.setenv("FEAHIP_RENUMBER", "0")
+    t = feahip.FeaSolver(deck); t.set_nodes(x)
+    assert np.array_equal(t.node_numbering(), np.arange(len(deck.nodes)))
+    t.set_assembly(feahip.ASM_STAGED); t.create_stiffness_and_residual()
+    off2, idx2, val2 = t.matrix_yale(); f2 = t.forces()
+    monkeypatch.delenv("FEAHIP_RENUMBER")
+    assert np.array_equal(off, off2) and np.array_equal(idx, idx2)
+    kscale, fscale = np.abs(val2).max(), np.abs(f2).max()
+    assert np.abs(val - val2).max() < 1e-13 * kscale and np.abs(f - f2).max() < 1e-13 * fscale
+    assert np.abs(f_only - f2).max() < 1e-13 * fscale
+    # the same mesh handed in brick-numbered: the library keeps it; mapped back to lexicographic ids the values are the
+    # renumbered context's, bit for bit (same library numbering, same maps, same kernel)
+    bdeck = mesh.bar_deck(dims=dims, brick=(4, 2, 2))
+    new_id = mesh.brick_numbering(dims[0] + 1, dims[1] + 1, dims[2] + 1, (4, 2, 2))
+    b = feahip.FeaSolver(bdeck)
+    xb = np.empty_like(x); xb[new_id] = x
+    b.set_nodes(xb); b.create_stiffness_and_residual()
+    assert b.assembly_in_use() == feahip.ASM_GATHER
+    fb = b.forces().reshape(-1, 3)
+    assert np.array_equal(fb[new_id].ravel(), f)
+    s.close(); t.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_configuration_sharded(n):
+    """The same configuration over 2 and 3 in-process ranks: every rank's rows (a slab of library ids = a scattered set
+    of the caller's) equal the unsharded ones; K to rounding (the chunks of a shard start at its first row), the
+    residual to the bit."""
+    deck = mesh.bar_deck(dims=(4, 40, 4))
+    x = mesh.deformed_state(deck.nodes)
+    one = feahip.FeaSolver(deck); one.set_nodes(x); one.create_stiffness_and_residual()
+    off, idx, val = one.matrix_yale(); f = one.forces()
+    row_node = np.repeat(np.arange(one.ndof), np.diff(off)) // 3
+    g = feahip.FeaGroup(deck, n)
+    g.each("set_nodes", x); g.each("create_stiffness_and_residual")
+    seen = np.zeros(len(deck.nodes), dtype=int)
+    for nd, r in zip(g.nodes, g.ranks):
+        assert r.assembly_in_use() == feahip.ASM_GATHER
+        seen[nd] += 1
+        own = np.zeros(len(deck.nodes), dtype=bool); own[nd] = True
+        mine = own[row_node]
+        _, _, v = r.matrix_yale()
+        assert np.abs(v[mine] - val[mine]).max() < 4e-16 * np.abs(val).max()
+        assert np.all(v[~mine] == 0)
+        d = r.owned_dofs()
+        assert np.array_equal(r.forces()[d], f[d])
+    assert np.all(seen == 1)
+    g.close(); one.close()
+
+
+@pytest.mark.gpu
+def test_reshard_with_a_shard_the_gather_maps_do_not_fit():
+    """One context re-sharded back and forth: a bar with a fan of 230 tetrahedra welded on near one end, whose hub row
+    exceeds the gather chunk limits.  The shard that holds the hub must fall back (no stale maps of the previous shard
+    launched against the new K window), the other shard must still use the gather kernel, and going back must work."""
+    deck0 = mesh.bar_deck(dims=(3, 24, 3))
+    nodes = [tuple(p) for p in deck0.nodes]
+    el = [list(e) for e in deck0.elements]
+    N0 = len(nodes)
+    hub = 0                                                   # a corner node of the face y = 1
+    m = 230
+    ang = np.pi * (0.05 + 0.9 * np.arange(m + 1) / m)
+    c = np.array(nodes[hub])
+    ring = [tuple(c + 0.2 * np.array([-np.sin(a) * 0.7, -0.6, -np.cos(a) * 0.7])) for a in ang]
+    apex = tuple(c + np.array([-0.05, -0.25, -0.05]))
+    nodes += ring + [apex]
+    for i in range(m):
+        el.append([hub, N0 + i + 1, N0 + i, N0 + m + 1])
+    nodes = np.array(nodes); el = np.array(el, dtype=np.int32)
+    # orientation: flip any inverted tet
+    p = nodes[el]
+    vol = np.einsum("ij,ij->i", np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]), p[:, 3] - p[:, 0])
+    el[vol < 0] = el[vol < 0][:, [0, 2, 1, 3]]
+    deck = feahip.Deck(nodes=nodes, elements=el, ele_type=feahip.TETRAHEDRA4, gauss_nodes_count=1,
+                       presc_node=deck0.presc_node, presc_type=deck0.presc_type, presc_values=deck0.presc_values)
+    x = nodes * np.array([1.01, 1.02, 0.99])
+    o = OracleSolver(deck); o.set_nodes(x); o.update_state(); o.create_stiffness(); o.create_residual_forces()
+    s = feahip.FeaSolver(deck); s.set_nodes(x)
+    off = o.offsets()
+    row_node = np.repeat(np.arange(s.ndof), np.diff(off)) // 3
+    used = set()
+    for rank in (0, 1, 0, 1):
+        s.set_row_shard(rank, 2)
+        s.create_stiffness_and_residual()
+        used.add((rank, s.assembly_in_use()))
+        nd = s.owned_nodes()
+        own = np.zeros(len(nodes), dtype=bool); own[nd] = True
+        mine = own[row_node]
+        _, _, v = s.matrix_yale()
+        assert np.abs(v[mine] - o.values()[mine]).max() < 1e-12 * np.abs(o.values()).max()
+        assert np.all(v[~mine] == 0)
+        d = s.owned_dofs()
+        assert np.abs(s.forces()[d] - o.forces()[d]).max() < 1e-12 * np.abs(o.forces()).max()
+    kinds = {r: {k for (rr, k) in used if rr == r} for r in (0, 1)}
+    assert feahip.ASM_GATHER in (kinds[0] | kinds[1])         # the shard without the hub
+    assert any(k != {feahip.ASM_GATHER} for k in kinds.values())   # the shard with it fell back
+    s.close(); o.close()
