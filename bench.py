@@ -52,11 +52,23 @@ def pmc_traffic(args, world, kernel):
         return None, None
     try:
         rec = json.load(open(path))
-        if rec.get("kernel") != kernel or rec.get("numbering") != args.numbering:
-            return None, None
-        return rec["assembly_bytes_per_launch"], {k: rec.get(k) for k in ("commit", "source", "fetch_correction")}
+        # the library numbers the nodes itself now: every numbering of the caller ends in the same bricks
+        if rec.get("kernel") != kernel or rec.get("code_sha256") != kernel_code_hash():
+            return None, None                       # measured for other code: a stale constant is dropped, not printed
+        return rec["assembly_bytes_per_launch"], {k: rec.get(k) for k in ("commit", "source", "fetch_correction", "code_sha256")}
     except Exception:                               # noqa: BLE001
         return None, None
+
+
+def kernel_code_hash():
+    """sha256 over the sources the dominant assembly kernel and its maps are built from: profiles/pmc_traffic.json
+    carries the hash its PMC passes were measured at."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels_gather.hip", "gather_device.h", "gather.cpp", "fem_device.h", "renumber.cpp"):
+        with open(os.path.join(ROOT, "fea-large_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def cpu_baseline(n_sample, quadratic=False, model=None):
@@ -133,9 +145,11 @@ def main():
                     help="n of the CPU-baseline sample block (0 = skip; default: ~10 s of single-core work, 48 for TET4, 14 for TET10)")
     ap.add_argument("--no-newton", action="store_true", help="skip the single full Newton iteration")
     ap.add_argument("--assembly", default="auto", help="assembly strategy: auto | gather | staged | ... (fea_hip.h)")
-    ap.add_argument("--numbering", default="brick", help="node numbering of the synthetic block: 'brick' = bricks of "
-                    "4x2x2 nodes, 3x4x4 half-grid nodes with --quadratic (SURVEY 8d allows a locality numbering), 'lex' = x fastest, z, y slowest, or bx,by,bz")
+    ap.add_argument("--numbering", default="lex", help="node numbering the CALLER hands in: 'lex' = x fastest, z, y slowest (default; the "
+                    "library numbers the nodes itself, csrc/renumber.cpp), 'brick' = bricks of 4x4x4 nodes (3x4x4 half-grid nodes with "
+                    "--quadratic), or bx,by,bz")
     ap.add_argument("--cpu-single-only", action="store_true", help="skip the one-oracle-copy-per-core CPU baseline")
+    ap.add_argument("--no-tet10", action="store_true", help="skip the small TET10 leg of extras")
     args = ap.parse_args()
     if args.cpu_sample is None:
         args.cpu_sample = 0 if args.hex else 14 if args.quadratic else 48     # (the CPU legs are wired for the tet blocks)
@@ -180,9 +194,9 @@ def main():
             dist.barrier()
 
     t_setup = time.perf_counter()
-    # 'brick': 4x2x2 nodes for linear tetrahedra, 3x4x4 nodes of the half-spacing grid for 10-node tetrahedra (48 rows: one
+    # 'brick': 4x4x4 nodes for linear tetrahedra, 3x4x4 nodes of the half-spacing grid for 10-node tetrahedra (48 rows: one
     # gather chunk of kernels_gather10.hip), 4x4x4 nodes for 8-node bricks
-    brick = (None if args.numbering == "lex" else ((3, 4, 4) if args.quadratic else (4, 4, 4) if args.hex else (4, 2, 2)) if args.numbering == "brick"
+    brick = (None if args.numbering == "lex" else ((3, 4, 4) if args.quadratic else (4, 4, 4)) if args.numbering == "brick"
              else tuple(int(v) for v in args.numbering.split(",")))
     deck = mesh.bar_deck(n=args.n, quadratic=args.quadratic, hexa=args.hex, recipe="clamped", model=model, brick=brick,
                          solver_type=feahip.PCG_ILU, solver_tolerance=1e-14, solver_max_iter=20000)
@@ -233,6 +247,34 @@ def main():
     value = E_total * args.steps / dt
 
     share = 1.0 / world
+    renumbered = not np.array_equal(solver.node_numbering(), np.arange(N))
+    # ---- one untimed cross-check of the K the timed launches assemble: its product with a random vector against the
+    # product of the K a second, independent kernel assembles from the same state (staged visits / the generic
+    # row-owner kernel), K . translation = 0, and symmetry by <a, K b> = <b, K a>
+    verified = None
+    if world == 1:
+        try:
+            rng = np.random.default_rng(66)
+            va, vb = rng.normal(size=3 * N), rng.normal(size=3 * N)
+            ya, yb = solver.spmv(va), solver.spmv(vb)
+            tr = np.zeros(3 * N); tr[1::3] = 1.0
+            ok = bool(np.abs(solver.spmv(tr)).max() < 1e-10 * np.abs(ya).max() and abs(vb @ ya - va @ yb) < 1e-10 * abs(vb @ ya))
+            other = feahip.ASM_ROWOWNER if (args.quadratic or args.hex) else feahip.ASM_STAGED
+            if in_use != other:
+                solver.set_assembly(other)
+                solver.create_stiffness_and_residual()
+                ok = ok and bool(np.abs(solver.spmv(va) - ya).max() < 1e-11 * np.abs(ya).max())
+                solver.set_assembly(getattr(feahip, "ASM_" + args.assembly.upper()))
+                solver.create_stiffness_and_residual()
+                solver.sync()
+            verified = ok
+        except Exception as e:                      # noqa: BLE001
+            verified = f"check failed to run: {e}"
+    copy_gbps = None
+    try:
+        copy_gbps = solver.copy_bandwidth(1 << 30)
+    except Exception as e:                          # noqa: BLE001
+        print(f"copy bandwidth not measured: {e}", file=sys.stderr)
     # dominant kernel, HIP events on the library's own stream (local, no collective)
     k_ms = solver.time_kernel(0, warmup=2, iters=max(5, args.steps))
     B = algorithmic_bytes(sz["npe"], E_total, N, nnz) * share
@@ -247,10 +289,37 @@ def main():
         "aux_map_bytes_per_element": sz["aux_bytes"] / E_total,
         "rccl_sharded_solve": comm_ok if world > 1 else None,
         "device_bytes_this_rank": int(dev_bytes),
-        "node_numbering": ("lexicographic (x fastest, z, y slowest)" if brick is None else
-                           "bricks of %dx%dx%d nodes, bricks and nodes inside a brick lexicographic (SURVEY 8d allows a locality numbering)" % brick),
+        "node_numbering": ("caller: " + ("lexicographic (x fastest, z, y slowest)" if brick is None else "bricks of %dx%dx%d nodes" % brick) +
+                           "; library: " + ("renumbered to compact cells (csrc/renumber.cpp)" if renumbered else "the caller's ids kept")),
+        "verified": verified,
+        "copy_bandwidth_GBps": copy_gbps,
+        "assembly_frac_of_copy_bandwidth": achieved / copy_gbps if copy_gbps else None,
+        "device_addresses_mod_2MiB": {k: v % (1 << 21) for k, v in solver.device_layout().items()},
     }
+
+    # ---- the reference's own element next to the headline: 10-node tetrahedra / 5 Gauss points on a small block
+    # (24 x 144 x 24 cubes, 497 664 elements, a few ms), same deformed state, what AUTO runs
+    tet10 = None
+    if world == 1 and not args.quadratic and not args.hex and not args.no_tet10:
+        try:
+            d10 = mesh.bar_deck(n=24, quadratic=True, recipe="clamped", model=model)
+            s10 = feahip.FeaSolver(d10, device=local)
+            s10.set_nodes(mesh.deformed_state(d10.nodes))
+            s10.create_stiffness_and_residual(); s10.sync()
+            z10 = s10.sizes()
+            ms10 = s10.time_kernel(0, warmup=10, iters=20)
+            B10 = algorithmic_bytes(10, z10["E"], z10["N"], z10["nnzb"] * 9)
+            tet10 = {"workload": f"{z10['E']} TET10/5GP {args.model} block (24x144x24 Kuhn cubes), stiffness+residual, caller numbering lexicographic",
+                     "assembly_ms": ms10, "elements_per_s": z10["E"] / (ms10 * 1e-3), "algorithmic_GBps": B10 / (ms10 * 1e-3) / 1e9,
+                     "hbm_frac": B10 / (ms10 * 1e-3) / 1e9 / HBM_PEAK_GBS, "fp64_vector_frac": 27e3 * z10["E"] / (ms10 * 1e-3) / 78.6e12,
+                     "kernel": "k_state10 + k_assemble_gather10" if s10.assembly_in_use() == feahip.ASM_GATHER else str(s10.assembly_in_use()),
+                     "residual_only_ms": s10.time_kernel(2, warmup=5, iters=10)}
+            s10.close()
+        except Exception as e:                      # noqa: BLE001
+            tet10 = {"failed": str(e)}
     traffic, traffic_src = pmc_traffic(args, world, kernel)
+    if tet10 is not None:
+        extras["tet10"] = tet10
     out = {
         "metric": "element-stiffness assemblies/sec", "value": value, "unit": "elements/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

@@ -804,10 +804,54 @@ extern "C" int feahip_time_kernel(feahip_ctx *c, int what, int warmup, int iters
   return FEAHIP_OK;
 }
 
+// plain streaming copy, 16 bytes per lane: the copy bandwidth of THIS box, the figure the roofline fractions can be
+// quoted against next to the 8 TB/s of the data sheet (MI355X_MICROARCH.md measures 6.29 TB/s this way)
+__global__ __launch_bounds__(256)
+void k_copy16(const double2 *__restrict__ src, double2 *__restrict__ dst, size_t n)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+extern "C" int feahip_copy_bandwidth(feahip_ctx *c, long long bytes, double *gbytes_per_s)
+{
+  CTX_GUARD_NOK(c);
+  if (!gbytes_per_s || bytes < (1 << 20)) return FEAHIP_EINVAL;
+  const size_t n = (size_t)bytes / 16;
+  double2 *a = nullptr, *b = nullptr;
+  FEA_HIP_CHECK(c, hipMalloc((void **)&a, n * 16));
+  if (hipMalloc((void **)&b, n * 16) != hipSuccess) { (void)hipFree(a); c->err = "out of device memory"; return FEAHIP_ENOMEM; }
+  (void)hipMemsetAsync(a, 0x3c, n * 16, c->stream);
+  const int grid = 256 * 16;
+  for (int k = 0; k < 3; ++k) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, c->stream, a, b, n);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, c->stream);
+  const int reps = 10;
+  for (int k = 0; k < reps; ++k) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, c->stream, a, b, n);
+  (void)hipEventRecord(e1, c->stream);
+  const hipError_t err = hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(a); (void)hipFree(b);
+  if (err != hipSuccess || !(ms > 0)) { c->err = "copy kernel failed"; return FEAHIP_EHIP; }
+  *gbytes_per_s = 2.0 * (double)(n * 16) * reps / ((double)ms * 1e-3) / 1e9;      // read + written
+  return FEAHIP_OK;
+}
+
 extern "C" int feahip_assembly_in_use(feahip_ctx *c, int *strategy)
 {
   if (!c || !strategy) return FEAHIP_EINVAL;
   *strategy = c->last_strategy;
+  return FEAHIP_OK;
+}
+
+extern "C" int feahip_device_layout(feahip_ctx *c, long long *o)
+{
+  if (!c || !o) return FEAHIP_EINVAL;
+  { const int rc = ensure_k(c); if (rc) return rc; }
+  o[0] = (long long)(size_t)c->d_K_base; o[1] = (long long)(size_t)c->d_colidx; o[2] = (long long)(size_t)c->d_p; o[3] = (long long)(size_t)c->d_q;
   return FEAHIP_OK;
 }
 

@@ -258,10 +258,29 @@ int launch_assemble_quad(feahip_ctx *c, bool doF);
 // Per chunk the host prepares one fixed-stride record: header, the chunk's nodes (owned rows first), its distinct
 // elements as 4 chunk-local node ids, and per off-diagonal block the list of (element, local row node, local
 // column node) contributions that sum to it; per residual thread a slice of one row's (element, local node) visits.
-#define FEA_G_THREADS 256
+#ifndef FEA_G_BIG
+#define FEA_G_BIG 1
+#endif
+#if FEA_G_BIG
+#define FEA_G_THREADS 1024            // one workgroup per CU: sixteen waves share one chunk's records (see kernels_gather.hip)
+#define FEA_G_TASK_THREADS 768        // block and residual threads: waves 0-11; waves 12-15 (FEA_G_DIAG_LANES) sum the diagonal blocks
+#define FEA_G_MAX_ROWS 64
+#define FEA_G_MAX_NODES 256           // 8-bit chunk-local node slots
+#define FEA_G_MAX_ELEMS 719           // slots come in sixteens and one stays all-zero; 45 x 16 = 720 records of 208 B fill the LDS next to the coordinates
+#define FEA_G_ELEMS_TARGET 672        // a 4 x 4 x 4 brick of nodes of a Kuhn block
+#define FEA_G_CELL 4, 4, 4
+#else
+#define FEA_G_THREADS 256             // three workgroups per CU
+#define FEA_G_TASK_THREADS 192
 #define FEA_G_MAX_ROWS 16
 #define FEA_G_MAX_NODES 128
-#define FEA_G_MAX_ELEMS 239           // 8-bit record slot, slots come in sixteens and one stays all-zero
+#define FEA_G_MAX_ELEMS 239
+#define FEA_G_ELEMS_TARGET 216        // a 4 x 2 x 2 brick
+#define FEA_G_CELL 4, 2, 2
+#endif
+#define FEA_G_DIAG_LANES (FEA_G_THREADS - FEA_G_TASK_THREADS)
+#define FEA_G_SLOT_BITS 10            // record slot inside a contribution / visit entry: slot | la << 10 | lb << 12
+#define FEA_G_MAX_SLOTS 1024
 #define FEA_G_REGW 4                  // contribution words a block thread keeps in registers (2 entries each)
 struct GatherHeader {                // 64 bytes, first thing in a chunk record
   int r0, r1, b0, nb;                // rows [r0, r1), blocks [b0, b0+nb) of the CSR
@@ -288,8 +307,6 @@ struct HostGather {
 void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int row_lo, int row_hi, HostGather &out);
 int ensure_gather(feahip_ctx *c);
 int launch_assemble_gather(feahip_ctx *c, bool doK, bool doF);
-bool gather_pc_fits(const feahip_ctx *c);                      // kernels_gather_pc.hip: producer / consumer waves, one workgroup per CU
-int launch_assemble_gather_pc(feahip_ctx *c, bool doF);
 
 // GATHER assembly of 10-node tetrahedra (kernels_gather10.hip, gather10.cpp).  Same idea as the 4-node one with the
 // Gauss points as an outer loop: a 256-thread workgroup owns up to 64 consecutive block rows, evaluates every

@@ -50,10 +50,14 @@ inline int b128_group(int t)
 
 // u16 offsets inside the "rows" section
 #define G_RS 0                        // rstart[MAX_ROWS + 1]
-#define G_RD 20                       // rdiag[MAX_ROWS]
-#define G_VF 40                       // vfirst[MAX_ROWS + 1]
-#define G_ROWS_U16 64
-#define G_TASK_THREADS 192             // block and residual threads: waves 0-2; wave 3 sums the diagonal blocks
+#define G_RD 66                       // rdiag[MAX_ROWS]
+#define G_VF 130                      // vfirst[MAX_ROWS + 1]
+#define G_ROWS_U16 200
+#define G_TASK_THREADS FEA_G_TASK_THREADS   // block and residual threads; the remaining waves sum the diagonal blocks
+#define G_SLOT(w) ((w) & 1023u)
+#define G_LA(w) (((w) >> 10) & 3)
+#define G_LB(w) (((w) >> 12) & 3)
+#define G_NGROUPS (FEA_G_THREADS / 16) // 16-lane groups of a workgroup's ds_read_b128
 
 void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int row_lo, int row_hi, HostGather &out)
 {
@@ -61,7 +65,7 @@ void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int
   out.ok = false; out.nchunks = 0; out.blob.clear(); out.first_row.clear();
   if (row_lo < 0 || row_hi > N || row_lo >= row_hi) return;
   // limits of one chunk; the element target keeps three workgroups' records in one CU's LDS
-  int max_rows = FEA_G_MAX_ROWS, max_elems = 216, alpha = 24;
+  int max_rows = FEA_G_MAX_ROWS, max_elems = FEA_G_ELEMS_TARGET, alpha = 24;
   if (const char *e = getenv("FEAHIP_GATHER_ROWS")) max_rows = std::max(1, std::min(FEA_G_MAX_ROWS, atoi(e)));
   if (const char *e = getenv("FEAHIP_GATHER_ELEMS")) max_elems = std::max(8, std::min(FEA_G_MAX_ELEMS, atoi(e)));
   if (const char *e = getenv("FEAHIP_GATHER_ALPHA")) alpha = std::max(0, atoi(e));
@@ -174,7 +178,7 @@ void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int
       nd.erase(std::unique(nd.begin(), nd.end()), nd.end());
       const int nnode = (int)nd.size(), nelem = (int)el.size();
       const int nslots = 16 * ((nelem + 1 + 15) / 16), nnslots = 16 * ((nnode + 15) / 16);
-      if (nnslots > FEA_G_MAX_NODES || nslots > 256 || nrows > FEA_G_MAX_ROWS) { bad[p] = 1; continue; }
+      if (nnslots > FEA_G_MAX_NODES || nslots > FEA_G_MAX_SLOTS || nrows > FEA_G_MAX_ROWS) { bad[p] = 1; continue; }
       auto lnode = [&](int g) { return (int)(std::lower_bound(nd.begin(), nd.end(), g) - nd.begin()); };
       auto lelem = [&](int e) { return (int)(std::lower_bound(el.begin(), el.end(), e) - el.begin()); };
       // block threads: the off-diagonal blocks in CSR order; a block whose column is a LOWER row of the same chunk
@@ -211,14 +215,14 @@ void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int
         for (int q = hp.incptr[a]; q < hp.incptr[a + 1]; ++q, ++kv) {
           const int e = (int)(hp.inc_rows[q] & 0x0FFFFFFFu), la = (int)(hp.inc_rows[q] >> 28);
           const int le = lelem(e);
-          dl[(size_t)4 * (a - r0) + (kv & 3)].push_back((uint16_t)(le | (la << 8)));
+          dl[(size_t)4 * (a - r0) + (kv & 3)].push_back((uint16_t)(le | (la << 10)));
           for (int lb = 0; lb < 4; ++lb) {
             if (lb == la) continue;
             const int b = conn[(size_t)e * 4 + lb];
             if (b == a) continue;                 // degenerate element (repeated node): no off-diagonal block
             const int pos = hp.rowptr[a] + (int)(std::lower_bound(cb, ce, b) - cb) - b0;
             if (tid_of[pos] < 0) continue;        // served by the mirror block's thread
-            lists[(size_t)tid_of[pos]].push_back((uint16_t)(le | (la << 8) | (lb << 10)));
+            lists[(size_t)tid_of[pos]].push_back((uint16_t)(le | (la << 10) | (lb << 12)));
           }
         }
       }
@@ -236,7 +240,7 @@ void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int
       reads.assign((size_t)nelem, std::vector<Read>());
       const int nsteps = std::max(2 * dwords, 2 * ddwords);
       auto add_reads = [&](int lane, int step, uint16_t w, bool diag) {
-        const int le = w & 255, la = (w >> 8) & 3, lb = (w >> 10) & 3;
+        const int le = (int)G_SLOT(w), la = G_LA(w), lb = G_LB(w);
         const int grp = b128_group(lane);
         // kinds: 0 P_a, 1 Z_a, 2 P_b, 3 Q_b, 4 Z_b, 5 VV   (diagonal visit: P_a, Z_a, Q_a, VV)
         const int offs[6] = {la, 8 + la, diag ? 4 + la : lb, diag ? -1 : 4 + lb, diag ? -1 : 8 + lb, 12};
@@ -247,7 +251,7 @@ void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int
         for (size_t k = 0; k < lists[t].size(); ++k) add_reads(t, (int)k, lists[t][k], false);
       for (int l = 0; l < 4 * nrows; ++l)
         for (size_t k = 0; k < dl[l].size(); ++k) add_reads(G_TASK_THREADS + l, (int)k, dl[l][k], true);
-      const int nsets = 16 * nsteps * 6;
+      const int nsets = G_NGROUPS * nsteps * 6;
       occ.assign((size_t)nsets * 16, 0);
       eslot.assign((size_t)nelem, -1);
       std::vector<int> cap(16, nslots / 16), res((size_t)nelem, -1);
@@ -297,7 +301,7 @@ void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int
         std::vector<std::vector<uint16_t>> nreads((size_t)nnode);
         for (int e = 0; e < nelem; ++e)
           for (int k = 0; k < 4; ++k) nreads[lnode(conn[(size_t)el[e] * 4 + k])].push_back((uint16_t)(b128_group(eslot[e]) * 4 + k));
-        std::vector<uint8_t> nocc((size_t)16 * 4 * 16, 0);    // 16 lane groups x 4 node positions x 16 slots
+        std::vector<uint8_t> nocc((size_t)G_NGROUPS * 4 * 16, 0);    // lane groups x 4 node positions x 16 slots
         std::vector<int> ncap(16, nnslots / 16), nres((size_t)nnode, -1), nord((size_t)nnode);
         for (int i = 0; i < nnode; ++i) { nord[i] = i; std::sort(nreads[i].begin(), nreads[i].end()); nreads[i].erase(std::unique(nreads[i].begin(), nreads[i].end()), nreads[i].end()); }
         std::stable_sort(nord.begin(), nord.end(), [&](int a, int b) { return nreads[a].size() > nreads[b].size(); });
@@ -328,15 +332,15 @@ void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int
         for (int k = 0; k < 4; ++k) w |= (uint32_t)nslot[lnode(conn[(size_t)el[i] * 4 + k])] << (8 * k);
         L.elems[eslot[i]] = w;
       }
-      auto reslot = [&](uint16_t w) { return (uint16_t)((w & 0xFF00u) | (uint16_t)eslot[w & 255]); };
+      auto reslot = [&](uint16_t w) { return (uint16_t)((w & 0xFC00u) | (uint16_t)eslot[G_SLOT(w)]); };
       L.clist.assign((size_t)dwords * 2 * FEA_G_THREADS, (uint16_t)zslot);
       for (int t = 0; t < ntask; ++t)
         for (size_t k = 0; k < lists[t].size(); ++k)
           L.clist[((size_t)(k / 2) * FEA_G_THREADS + t) * 2 + (k & 1)] = reslot(lists[t][k]);
-      L.dlist.assign((size_t)ddwords * 2 * 64, (uint16_t)zslot);
+      L.dlist.assign((size_t)ddwords * 2 * FEA_G_DIAG_LANES, (uint16_t)zslot);
       for (int l = 0; l < 4 * nrows; ++l)
         for (size_t k = 0; k < dl[l].size(); ++k)
-          L.dlist[((size_t)(k / 2) * 64 + l) * 2 + (k & 1)] = reslot(dl[l][k]);
+          L.dlist[((size_t)(k / 2) * FEA_G_DIAG_LANES + l) * 2 + (k & 1)] = reslot(dl[l][k]);
       // residual threads (waves 0-2): slices of vdepth visits of one row
       int vdepth = 1;
       for (;; ++vdepth) {
@@ -356,7 +360,7 @@ void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int
         int k = 0;
         for (int q = hp.incptr[a]; q < hp.incptr[a + 1]; ++q, ++k) {
           const int e = (int)(hp.inc_rows[q] & 0x0FFFFFFFu), la = (int)(hp.inc_rows[q] >> 28);
-          L.vlist[(size_t)(k % vdepth) * FEA_G_THREADS + t0 + k / vdepth] = (uint16_t)(eslot[lelem(e)] | (la << 8));
+          L.vlist[(size_t)(k % vdepth) * FEA_G_THREADS + t0 + k / vdepth] = (uint16_t)(eslot[lelem(e)] | (la << 10));
         }
       }
       GatherHeader &h = L.h;
@@ -474,7 +478,7 @@ void gather_row_digest(const HostGather &hg, const HostPattern &hp, unsigned lon
       const int a = row_of(bpos), b = hp.colidx[h.b0 + bpos];
       for (int k = 0; k < 2 * h.depth; ++k) {
         const uint16_t w = clist[((size_t)(k / 2) * FEA_G_THREADS + t) * 2 + (k & 1)];
-        const int slot = w & 255, la = (w >> 8) & 3, lb = (w >> 10) & 3;
+        const int slot = (int)G_SLOT(w), la = G_LA(w), lb = G_LB(w);
         if (elems[slot] == 0xFFFFFFFFu) continue;     // empty list slot
         int g[4];
         element_nodes(slot, g);
@@ -484,8 +488,8 @@ void gather_row_digest(const HostGather &hg, const HostPattern &hp, unsigned lon
     }
     for (int l = 0; l < 4 * (h.r1 - h.r0); ++l)
       for (int k = 0; k < 2 * h.ddepth; ++k) {
-        const uint16_t w = dlist[((size_t)(k / 2) * 64 + l) * 2 + (k & 1)];
-        const int slot = w & 255, la = (w >> 8) & 3;
+        const uint16_t w = dlist[((size_t)(k / 2) * FEA_G_DIAG_LANES + l) * 2 + (k & 1)];
+        const int slot = (int)G_SLOT(w), la = G_LA(w);
         if (elems[slot] == 0xFFFFFFFFu) continue;
         int g[4];
         element_nodes(slot, g);

@@ -1,6 +1,5 @@
 // gather_device.h -- device helpers shared by the GATHER assembly kernels of linear tetrahedra
-// (kernels_gather.hip: four phases per chunk, three workgroups per CU; kernels_gather_pc.hip: producer and
-// consumer waves, one workgroup per CU): the element record and its LDS layout, one contribution to a block,
+// (kernels_gather.hip): the element record and its LDS layout, one contribution to a block,
 // the map words a thread holds.  Algebra of fem_device.h; replaces fea_solver.c:873-883, :887-1068, :1072-1114
 // for TETRAHEDRA4 meshes.
 #pragma once
@@ -39,9 +38,12 @@ struct GatherArgs {
 #define G_STAMP(i) do { } while (0)
 #endif
 
-#define G_RS 0
-#define G_RD 20
-#define G_VF 40
+#define G_RS 0                        // u16 offsets inside the "rows" section: rstart[MAX_ROWS + 1]
+#define G_RD 66                       // rdiag[MAX_ROWS]
+#define G_VF 130                      // vfirst[MAX_ROWS + 1]
+#define G_SLOT(w) ((w) & 1023u)       // contribution / visit entry: record slot | local row node << 10 | local column node << 12
+#define G_LA(w) (((w) >> 10) & 3)
+#define G_LB(w) (((w) >> 12) & 3)
 
 #define GREC 26                  // doubles per element record (stiffness): g[4][3], t[4][3], vl, vm
 #define GREC_F 12                // residual only: s[4][3] = vol sigma g
@@ -56,8 +58,8 @@ struct GatherArgs {
 struct GRead { double2 pa, za, pb, qb, zb, vv; };
 __device__ __forceinline__ GRead g_fetch(const double *sT, unsigned w)
 {
-  const double2 *T = reinterpret_cast<const double2 *>(sT + (w & 255u) * GREC);
-  const int la = (w >> 8) & 3, lb = (w >> 10) & 3;
+  const double2 *T = reinterpret_cast<const double2 *>(sT + G_SLOT(w) * GREC);
+  const int la = G_LA(w), lb = G_LB(w);
   GRead r;
   r.pa = T[la]; r.za = T[8 + la]; r.pb = T[lb]; r.qb = T[4 + lb]; r.zb = T[8 + lb]; r.vv = T[12];
   return r;
@@ -96,8 +98,8 @@ __device__ __forceinline__ GRead g_fetch_cheap(const double *sT, unsigned w)
 template <bool DOF>
 __device__ __forceinline__ void g_consume_diag(const double *sT, unsigned w, double (&a)[6], double (&fa)[3])
 {
-  const double2 *T = reinterpret_cast<const double2 *>(sT + (w & 255u) * GREC);
-  const int la = (w >> 8) & 3;
+  const double2 *T = reinterpret_cast<const double2 *>(sT + G_SLOT(w) * GREC);
+  const int la = G_LA(w);
   const double2 pa = T[la], qa = T[4 + la], za = T[8 + la], vv = T[12];
   const double s = vv.x + vv.y;
   const double d = pa.x * qa.x + pa.y * qa.y + za.x * za.y;
@@ -125,51 +127,18 @@ __device__ __forceinline__ void g_gather_batch(const double *sT, const unsigned 
   for (int k = 0; k < 2 * D; ++k) g_apply(r[k], acc);
 }
 
-struct GDiagRead { double2 pa, qa, za, vv; };
-__device__ __forceinline__ GDiagRead g_fetch_diag(const double *sT, unsigned w)
-{
-  const double2 *T = reinterpret_cast<const double2 *>(sT + (w & 255u) * GREC);
-  const int la = (w >> 8) & 3;
-  GDiagRead r;
-  r.pa = T[la]; r.qa = T[4 + la]; r.za = T[8 + la]; r.vv = T[12];
-  return r;
-}
-template <bool DOF>
-__device__ __forceinline__ void g_apply_diag(const GDiagRead &r, double (&a)[6], double (&fa)[3])
-{
-  const double2 pa = r.pa, qa = r.qa, za = r.za, vv = r.vv;
-  const double s = vv.x + vv.y;
-  const double d = pa.x * qa.x + pa.y * qa.y + za.x * za.y;
-  const double h0 = s * pa.x, h1 = s * pa.y, h2 = s * za.x;
-  a[0] += fma(h0, pa.x, d); a[1] = fma(h0, pa.y, a[1]); a[2] = fma(h0, za.x, a[2]);
-  a[3] += fma(h1, pa.y, d); a[4] = fma(h1, za.x, a[4]); a[5] += fma(h2, za.x, d);
-  if (DOF) {
-    fa[0] -= __dsub_rn(qa.x, __dmul_rn(vv.y, pa.x)); fa[1] -= __dsub_rn(qa.y, __dmul_rn(vv.y, pa.y)); fa[2] -= __dsub_rn(za.y, __dmul_rn(vv.y, za.x));
-  }
-}
-// list words [K0, K0 + D) of a diagonal lane: 2 D visits read, then summed
-template <int K0, int D, bool DOF>
-__device__ __forceinline__ void g_diag_batch(const double *sT, const unsigned (&cw)[FEA_G_REGW], double (&a)[6], double (&fa)[3])
-{
-  GDiagRead r[2 * D];
-#pragma unroll
-  for (int k = 0; k < D; ++k) { r[2 * k] = g_fetch_diag(sT, cw[K0 + k] & 0xFFFFu); r[2 * k + 1] = g_fetch_diag(sT, cw[K0 + k] >> 16); }
-#pragma unroll
-  for (int k = 0; k < 2 * D; ++k) g_apply_diag<DOF>(r[k], a, fa);
-}
-
 // residual contribution of one (element, local node) visit: -vol sigma g_a (fea_solver.c:1096-1109)
 template <bool DOK>
 __device__ __forceinline__ void g_visit(const double *sT, unsigned w, double (&fa)[3])
 {
-  const int la = (w >> 8) & 3;
+  const int la = G_LA(w);
   if (DOK) {
-    const double2 *T = reinterpret_cast<const double2 *>(sT + (w & 255u) * GREC);
+    const double2 *T = reinterpret_cast<const double2 *>(sT + G_SLOT(w) * GREC);
     const double2 pa = T[la], qa = T[4 + la], za = T[8 + la];
     const double vm = T[12].y;
     fa[0] -= qa.x - vm * pa.x; fa[1] -= qa.y - vm * pa.y; fa[2] -= za.y - vm * za.x;
   } else {
-    const double *T = sT + (w & 255u) * GREC_F;
+    const double *T = sT + G_SLOT(w) * GREC_F;
     const double2 pa = *reinterpret_cast<const double2 *>(T + 2 * la);
     fa[0] -= pa.x; fa[1] -= pa.y; fa[2] -= T[8 + la];
   }
@@ -315,7 +284,7 @@ struct GMaps {
   int kd, vb, ve;
 };
 
-#define G_TASK_THREADS 192           // block and residual threads: waves 0-2; wave 3 sums the diagonal blocks
+#define G_TASK_THREADS FEA_G_TASK_THREADS
 
 template <bool DOK, bool DOF>
 __device__ __forceinline__ void g_load_maps(const GatherLayout &lay, const unsigned char *rec, int t, GMaps &m)
@@ -334,12 +303,12 @@ __device__ __forceinline__ void g_load_maps(const GatherLayout &lay, const unsig
     for (int k = 0; k < FEA_G_REGW; ++k)
       if (k < lay.max_depth) m.cw[k] = reinterpret_cast<const unsigned *>(rec + lay.o_clist)[k * FEA_G_THREADS + t];
   }
-  if (DOK && t >= G_TASK_THREADS) {                   // wave 3: four lanes per row, the visits of its diagonal block
+  if (DOK && t >= G_TASK_THREADS) {                   // the last four waves: four lanes per row, the visits of its diagonal block
     const int l = t - G_TASK_THREADS;
     m.kd = rows[G_RD + (l >> 2)];
 #pragma unroll
     for (int k = 0; k < FEA_G_REGW; ++k)
-      if (k < lay.max_ddepth) m.cw[k] = reinterpret_cast<const unsigned *>(rec + lay.o_dlist)[k * 64 + l];
+      if (k < lay.max_ddepth) m.cw[k] = reinterpret_cast<const unsigned *>(rec + lay.o_dlist)[k * FEA_G_DIAG_LANES + l];
   }
   if (!DOK && t < ((lay.max_vthr + 63) & ~63)) {
 #pragma unroll

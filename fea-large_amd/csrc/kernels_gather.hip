@@ -39,7 +39,7 @@
 //     phase (the tile is dead from the end of the state phase), a whole state + gather phase after their request;
 //   * the finished rows of chunk i are stored last and nobody waits for them.
 template <bool DOK, bool DOF, bool NH>
-__global__ __launch_bounds__(FEA_G_THREADS, 3)
+__global__ __launch_bounds__(FEA_G_THREADS, FEA_G_BIG ? 4 : 3)
 void k_assemble_gather(GatherArgs A, int run_len)
 {
   extern __shared__ double2 g_smem[];
@@ -186,7 +186,7 @@ void k_assemble_gather(GatherArgs A, int run_len)
       for (int k = 0; k < FEA_G_REGW; ++k)
         if (k < h.ddepth) { g_consume_diag<DOF>(sT, m.cw[k] & 0xFFFFu, dg, fa); g_consume_diag<DOF>(sT, m.cw[k] >> 16, dg, fa); }
       for (int k = FEA_G_REGW; k < h.ddepth; ++k) {        // nodes with more than 32 elements around them
-        const unsigned w = reinterpret_cast<const unsigned *>(rec + A.lay.o_dlist)[k * 64 + t - G_TASK_THREADS];
+        const unsigned w = reinterpret_cast<const unsigned *>(rec + A.lay.o_dlist)[k * FEA_G_DIAG_LANES + t - G_TASK_THREADS];
         g_consume_diag<DOF>(sT, w & 0xFFFFu, dg, fa); g_consume_diag<DOF>(sT, w >> 16, dg, fa);
       }
     }
@@ -353,13 +353,6 @@ int launch_assemble_gather(feahip_ctx *c, bool doK, bool doF)
   A.K = c->d_K; A.f = c->d_f; A.bad = c->d_flag + 1; A.stamps = nullptr; A.ablate = 0;
   if (c->ngchunks <= 0) return FEAHIP_OK;
 #ifdef FEAHIP_DEBUG
-  // diagnostic build only: the producer / consumer form of this kernel (kernels_gather_pc.hip; measured slower,
-  // DESIGN.md section 4), FEAHIP_GATHER_PC=1
-  static int use_pc = -1;
-  if (use_pc < 0) { const char *e = getenv("FEAHIP_GATHER_PC"); use_pc = e ? atoi(e) : 0; }
-  if (doK && use_pc && gather_pc_fits(c)) return launch_assemble_gather_pc(c, doF);
-#endif
-#ifdef FEAHIP_DEBUG
   static unsigned long long *d_stamps = nullptr;
   static int stamps_cap = 0;
   { const char *e = getenv("FEAHIP_GATHER_ABLATE"); A.ablate = e ? atoi(e) : 0; }
@@ -374,8 +367,14 @@ int launch_assemble_gather(feahip_ctx *c, bool doK, bool doF)
     A.stamps = d_stamps;
   }
 #endif
-  static int run_len = -1;           // chunks per workgroup run (FEAHIP_GATHER_RUN: tuning only, results unchanged)
-  if (run_len < 0) { const char *e = getenv("FEAHIP_GATHER_RUN"); run_len = e && atoi(e) > 0 ? atoi(e) : 16; }
+  // chunks per workgroup run: one workgroup is resident per CU, so the runs are cut to give every CU the same number of
+  // them, two per CU (FEAHIP_GATHER_RUN: a fixed run length instead; tuning only, results unchanged)
+  static int run_env = -1;
+  if (run_env < 0) { const char *e = getenv("FEAHIP_GATHER_RUN"); run_env = e && atoi(e) > 0 ? atoi(e) : 0; }
+  static int ncu_of[64];
+  int &ncu = ncu_of[c->device & 63];
+  if (ncu <= 0) { hipDeviceProp_t p; ncu = (hipGetDeviceProperties(&p, c->device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
+  const int run_len = run_env ? run_env : (FEA_G_BIG ? std::max(1, (c->ngchunks + 2 * ncu - 1) / (2 * ncu)) : 16);
   const int nruns = (c->ngchunks + run_len - 1) / run_len;
   const dim3 grid((nruns + 7) & ~7), blk(FEA_G_THREADS);
   // LDS: coordinates (48 bytes per node slot) | element records, later the K tile (+1 double of alignment slack) and the residual partials

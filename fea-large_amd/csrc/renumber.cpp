@@ -3,8 +3,8 @@
 // The reference keeps the nodes in deck order (sexp_loader.c:170-215 stores them as they come; TetGen or
 // lexicographic ids) and its matrix rows follow (node * 3 + axis, fea_solver.c:377-384).  The assembly kernels here
 // own runs of CONSECUTIVE block rows and evaluate every element that touches them, so what a run of consecutive ids
-// looks like in space decides how often an element is evaluated: 2.3 times when 16 consecutive ids are a compact
-// 4 x 2 x 2 cluster, 2.9 times when they are a line of a lexicographic numbering.  feahip_create therefore numbers
+// looks like in space decides how often an element is evaluated: 1.75 times when 64 consecutive ids are a compact
+// 4 x 4 x 4 cluster, 2.9 times when they are lines of a lexicographic numbering.  feahip_create therefore numbers
 // the nodes itself and runs everything in that numbering; every entry of the ABI that takes or returns node-indexed
 // data (coordinates, forces, solution, prescribed node ids, the Yale matrix, SpMV vectors) translates, so the caller
 // only ever sees its own indexing (bit-exact connectivity / dof indexing: node * 3 + axis of the CALLER's node).
@@ -39,10 +39,9 @@ bool locality_numbering(int N, int E, int npe, const int *conn, const double *X 
   new_of_old.resize((size_t)N);
   for (int a = 0; a < N; ++a) new_of_old[a] = a;
   // nodes of a cell along (fastest, slowest, middle) axis: the chunk shapes the gather kernels want
-  // (16 rows for 4-node tetrahedra; 48 rows of the half-spacing grid for 10-node ones; 64 for 8-node bricks)
-  int cell[3] = {4, 2, 2};
+  // (64 rows for 4-node tetrahedra and 8-node bricks; 48 rows of the half-spacing grid for 10-node tetrahedra)
+  int cell[3] = {FEA_G_CELL};
   if (npe == 10) { cell[0] = 3; cell[1] = 4; cell[2] = 4; }
-  else if (npe == 8) { cell[0] = 4; cell[1] = 4; cell[2] = 4; }
   const int target = cell[0] * cell[1] * cell[2];
   if (N < 4 * target || E <= 0) return false;
   double lo[3] = {X[0], X[1], X[2]}, hi[3] = {X[0], X[1], X[2]};

@@ -75,6 +75,8 @@ ABI = {
     "feahip_host_assembly_digest": [C.c_int, C.c_int, C.c_int, _ip, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), _ip],
     "feahip_assembly_in_use": [C.c_void_p, _ip],
     "feahip_node_numbering": [C.c_void_p, _ip],
+    "feahip_copy_bandwidth": [C.c_void_p, C.c_longlong, _dp],
+    "feahip_device_layout": [C.c_void_p, C.POINTER(C.c_longlong)],
     "feahip_host_numbering": [C.c_int, C.c_int, C.c_int, _ip, _dp, _ip],
 }
 
@@ -474,6 +476,17 @@ class FeaSolver:
         self._chk(self._lib.feahip_sizes(self._ctx, o))
         keys = ["N", "E", "npe", "G", "nnzb", "nchunks", "aux_bytes", "max_rowlen"]
         return dict(zip(keys, [int(v) for v in o]))
+
+    def copy_bandwidth(self, nbytes=1 << 30):
+        """GB/s of a plain device copy (read + written) on this box."""
+        v = C.c_double(0)
+        self._chk(self._lib.feahip_copy_bandwidth(self._ctx, nbytes, C.byref(v)))
+        return v.value
+
+    def device_layout(self):
+        o = (C.c_longlong * 4)()
+        self._chk(self._lib.feahip_device_layout(self._ctx, o))
+        return {"K": int(o[0]), "colidx": int(o[1]), "p": int(o[2]), "q": int(o[3])}
 
     def assembly_in_use(self):
         """The strategy the most recent assembly launch ran (what ASM_AUTO resolved to)."""

@@ -286,6 +286,13 @@ int feahip_sync(feahip_ctx *ctx);
  * 1 stiffness only, 2 residual only, 3 SpMV, 4 one PCG iteration.           */
 int feahip_time_kernel(feahip_ctx *ctx, int what, int warmup, int iters,
                        double *avg_ms);
+/* Streaming copy of `bytes` bytes (16 bytes per lane, read + written counted)
+ * on the context's device and stream: the copy bandwidth of this box, to quote
+ * roofline fractions against next to the data-sheet peak.     */
+int feahip_copy_bandwidth(feahip_ctx *ctx, long long bytes, double *gbytes_per_s);
+/* device addresses of K, the column indices and the two SpMV vectors (for
+ * the alignment column of a bandwidth report): out4                         */
+int feahip_device_layout(feahip_ctx *ctx, long long *out4);
 /* sizes the roofline model needs: N, E, npe, G, block rows, blocks, and the
  * bytes of the auxiliary maps the kernels read                              */
 int feahip_sizes(feahip_ctx *ctx, long long *out8);

@@ -566,8 +566,7 @@ def test_feasolver_hip_command_line(decks_dir, tmp_path):
 
 def test_node_with_more_neighbours_than_the_spmv_tile():
     """A fan of 140 tetrahedra pairs around one node: its block row has 143 blocks, more than the 128-block LDS
-    tile of the SpMV / PCG kernels (and of the row-owner assembly).  Assembly must still be right (AUTO falls back
-    to the atomic scatter), and product and solve walk the long row with the lanes striding over its blocks: the
+    tile of the SpMV / PCG kernels (and of the row-owner assembly).  Assembly must still be right, and product and solve walk the long row with the lanes striding over its blocks: the
     reference's solvers have no row-length limit (fea_solver.c:300-321), so neither has this path."""
     m = 140
     ang = 2 * np.pi * np.arange(m) / m
@@ -586,7 +585,7 @@ def test_node_with_more_neighbours_than_the_spmv_tile():
     s, o = make_pair(deck, x)
     o.update_state(); o.create_stiffness(); o.create_residual_forces()
     s.create_stiffness_and_residual()
-    assert s.assembly_in_use() == feahip.ASM_ATOMIC
+    assert s.assembly_in_use() == feahip.ASM_GATHER            # (its 142 off-diagonal blocks fit the gather chunk's 768 block threads)
     off, idx, val = s.matrix_yale()
     assert np.array_equal(off, o.offsets()) and np.array_equal(idx, o.indexes())
     assert off[3] - off[0] == 3 * 3 * (m + 3)                  # the centre's three rows: 143 blocks

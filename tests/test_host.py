@@ -239,7 +239,7 @@ def test_host_map_builders_under_sanitizers(tmp_path):
     assert "patches=1 visits=1 pairs=1 gather=1/1" in r.stdout and "quad=1/1" in r.stdout and "gather10=1/1" in r.stdout and r.stdout.count("amg: ok=1") == 2
 
 
-@pytest.mark.parametrize("quadratic,brick", [(False, None), (False, (4, 2, 2)), (True, None), (True, (3, 4, 4))])
+@pytest.mark.parametrize("quadratic,brick", [(False, None), (False, (4, 4, 4)), (True, None), (True, (3, 4, 4))])
 def test_per_rank_assembly_maps_say_what_the_unsharded_maps_say(quadratic, brick):
     """A rank of a sharded run builds the assembly maps of ITS block rows only (gather chunks for linear and for
     10-node tets, shared-state chunks where those do not build), cut from its first row -- so they are not slices of the unsharded maps,

@@ -5,7 +5,7 @@ The reference keeps the nodes in deck order (sexp_loader.c:170-215) and its dof 
 axis -- runs everything in that numbering and translates at the ABI, so the caller keeps its own indexing bit-exactly.
 CPU tests: what the numbering is (host only).  GPU tests: every node-indexed entry of the ABI against the oracle in
 the CALLER's numbering, for a mesh the library renumbers; the timed configuration of bench.py (a lexicographically
-numbered block, which the library turns into bricks of 4 x 2 x 2 nodes) against the oracle, against the staged-visit
+numbered block, which the library turns into bricks of 4 x 4 x 4 nodes) against the oracle, against the staged-visit
 kernel on the caller's own numbering, sharded, and at its full size.
 """
 import gzip
@@ -28,14 +28,14 @@ def rel(a, b):
 # ---------------------------------------------------------------------------------------------- host only
 @pytest.mark.parametrize("n", [5, 13])
 def test_lattice_gets_brick_numbering(n):
-    """On a structured block the numbering IS the brick numbering the gather kernels were tuned on: 4 x 2 x 2 nodes
+    """On a structured block the numbering IS the brick numbering the gather kernels were tuned on: 4 x 4 x 4 nodes
     for linear tetrahedra, 3 x 4 x 4 half-grid nodes for 10-node ones, 4 x 4 x 4 for 8-node bricks; a deck that
     already has it is left alone."""
     lex = mesh.bar_deck(n=n)
     perm, renumbered = feahip.host_numbering(lex.elements, lex.nodes)
     assert renumbered
-    assert np.array_equal(perm, mesh.brick_numbering(n + 1, 6 * n + 1, n + 1, (4, 2, 2)))
-    brick = mesh.bar_deck(n=n, brick=(4, 2, 2))
+    assert np.array_equal(perm, mesh.brick_numbering(n + 1, 6 * n + 1, n + 1, (4, 4, 4)))
+    brick = mesh.bar_deck(n=n, brick=(4, 4, 4))
     perm2, renumbered2 = feahip.host_numbering(brick.elements, brick.nodes)
     assert not renumbered2 and np.array_equal(perm2, np.arange(len(brick.nodes)))
     q = mesh.bar_deck(n=4, quadratic=True)
@@ -155,7 +155,7 @@ def test_renumbered_context_speaks_the_callers_numbering(model):
 @pytest.mark.gpu
 def test_bench_configuration_gather_against_staged_visits_on_the_callers_ids(monkeypatch):
     """The configuration bench.py times, small: a lexicographically numbered TET4 block that the library numbers in
-    bricks of 4 x 2 x 2 nodes and assembles with the gather kernel -- against the SAME mesh in a context that keeps
+    bricks of 4 x 4 x 4 nodes and assembles with the gather kernel -- against the SAME mesh in a context that keeps
     the caller's ids (FEAHIP_RENUMBER=0) and runs the staged visits: K, f and the residual-only launch to rounding,
     patterns identical; and a brick-numbered deck (left alone) gives the same bits as the renumbered lexicographic one
     for the values the caller sees."""
@@ -178,8 +178,8 @@ def test_bench_configuration_gather_against_staged_visits_on_the_callers_ids(mon
     assert np.abs(f_only - f2).max() < 1e-13 * fscale
     # the same mesh handed in brick-numbered: the library keeps it; mapped back to lexicographic ids the values are the
     # renumbered context's, bit for bit (same library numbering, same maps, same kernel)
-    bdeck = mesh.bar_deck(dims=dims, brick=(4, 2, 2))
-    new_id = mesh.brick_numbering(dims[0] + 1, dims[1] + 1, dims[2] + 1, (4, 2, 2))
+    bdeck = mesh.bar_deck(dims=dims, brick=(4, 4, 4))
+    new_id = mesh.brick_numbering(dims[0] + 1, dims[1] + 1, dims[2] + 1, (4, 4, 4))
     b = feahip.FeaSolver(bdeck)
     xb = np.empty_like(x); xb[new_id] = x
     b.set_nodes(xb); b.create_stiffness_and_residual()
@@ -219,7 +219,7 @@ def test_bench_configuration_sharded(n):
 
 @pytest.mark.gpu
 def test_reshard_with_a_shard_the_gather_maps_do_not_fit():
-    """One context re-sharded back and forth: a bar with a fan of 230 tetrahedra welded on near one end, whose hub row
+    """One context re-sharded back and forth: a bar with a fan of 800 tetrahedra welded on near one end, whose hub row
     exceeds the gather chunk limits.  The shard that holds the hub must fall back (no stale maps of the previous shard
     launched against the new K window), the other shard must still use the gather kernel, and going back must work."""
     deck0 = mesh.bar_deck(dims=(3, 24, 3))
@@ -227,7 +227,7 @@ def test_reshard_with_a_shard_the_gather_maps_do_not_fit():
     el = [list(e) for e in deck0.elements]
     N0 = len(nodes)
     hub = 0                                                   # a corner node of the face y = 1
-    m = 230
+    m = 800
     ang = np.pi * (0.05 + 0.9 * np.arange(m + 1) / m)
     c = np.array(nodes[hub])
     ring = [tuple(c + 0.2 * np.array([-np.sin(a) * 0.7, -0.6, -np.cos(a) * 0.7])) for a in ang]
