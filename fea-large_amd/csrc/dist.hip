@@ -27,6 +27,23 @@ int install_shard(feahip_ctx *c, int rank, int nranks)
   build_shard_plan(c->h_rowptr, c->h_colidx, c->h_chunk, rank, nranks, plan);
   if (plan.row0 != c->row0 || plan.row1 != c->row1) release_k(c);     // K is re-allocated for the new rows on next use
   c->rank = rank; c->nranks = nranks; c->row0 = plan.row0; c->row1 = plan.row1;
+  {
+    // the longest run of this rank's SpMV chunks whose rows touch no halo column: they can be multiplied while the
+    // halo rows are in flight (a slab has its halo-touching chunks at its two ends)
+    int best_lo = 0, best_hi = 0, lo = -1;
+    for (int k = 0; k <= c->nchunks_local; ++k) {
+      bool interior = false;
+      if (k < c->nchunks_local) {
+        interior = true;
+        const int r0 = c->h_chunk[c->chunk0 + k], r1 = c->h_chunk[c->chunk0 + k + 1];
+        for (int q = c->h_rowptr[r0]; q < c->h_rowptr[r1] && interior; ++q)
+          if (c->h_colidx[q] < plan.row0 || c->h_colidx[q] >= plan.row1) interior = false;
+      }
+      if (interior) { if (lo < 0) lo = k; }
+      else if (lo >= 0) { if (k - lo > best_hi - best_lo) { best_lo = lo; best_hi = k; } lo = -1; }
+    }
+    c->ichunk_lo = best_lo; c->ichunk_hi = best_hi;
+  }
   c->peer = plan.peer; c->send_off = plan.send_off; c->recv_off = plan.recv_off;
   c->nsend = (int)plan.send_idx.size(); c->nrecv = (int)plan.recv_idx.size();
   for (void *p : {(void *)c->d_send_idx, (void *)c->d_recv_idx, (void *)c->d_send_buf, (void *)c->d_recv_buf})
@@ -73,6 +90,43 @@ struct RcclTransport : Transport {
     }
     if ((r = ncclGroupEnd()) != ncclSuccess) return fail(c, "ncclGroupEnd", r);
     feahip_enq_unpack(c, v, stride);
+    return FEAHIP_OK;
+  }
+  // the same exchange on a stream of its own: pack on the context's stream, send / receive / unpack on the
+  // communication stream, so that the product of the rows that touch no halo column runs meanwhile
+  int exchange_begin(std::vector<feahip_ctx *> &R, int which) override
+  {
+    feahip_ctx *c = R[0];
+    if (!c->comm_stream) {
+      FEA_HIP_CHECK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+      FEA_HIP_CHECK(c, hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
+      FEA_HIP_CHECK(c, hipEventCreateWithFlags(&c->ev_unpacked, hipEventDisableTiming));
+    }
+    const int stride = (which == 2) ? 4 : 3;
+    double *v = which == 0 ? c->d_p : (which == 1 ? c->d_u : (which == 2 ? c->d_x : c->d_z));
+    extern void feahip_enq_pack(feahip_ctx *, double *, int);
+    extern void feahip_enq_unpack_on(feahip_ctx *, double *, int, hipStream_t);
+    feahip_enq_pack(c, v, stride);
+    FEA_HIP_CHECK(c, hipEventRecord(c->ev_packed, c->stream));
+    FEA_HIP_CHECK(c, hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
+    ncclResult_t r = ncclGroupStart();
+    if (r != ncclSuccess) return fail(c, "ncclGroupStart", r);
+    for (size_t k = 0; k < c->peer.size(); ++k) {
+      const size_t ns = (size_t)3 * (c->send_off[k + 1] - c->send_off[k]), nr = (size_t)3 * (c->recv_off[k + 1] - c->recv_off[k]);
+      if (ns && (r = ncclSend(c->d_send_buf + (size_t)3 * c->send_off[k], ns, ncclDouble, c->peer[k], comm, c->comm_stream)) != ncclSuccess)
+        return fail(c, "ncclSend", r);
+      if (nr && (r = ncclRecv(c->d_recv_buf + (size_t)3 * c->recv_off[k], nr, ncclDouble, c->peer[k], comm, c->comm_stream)) != ncclSuccess)
+        return fail(c, "ncclRecv", r);
+    }
+    if ((r = ncclGroupEnd()) != ncclSuccess) return fail(c, "ncclGroupEnd", r);
+    feahip_enq_unpack_on(c, v, stride, c->comm_stream);
+    FEA_HIP_CHECK(c, hipEventRecord(c->ev_unpacked, c->comm_stream));
+    return FEAHIP_OK;
+  }
+  int exchange_end(std::vector<feahip_ctx *> &R) override
+  {
+    feahip_ctx *c = R[0];
+    FEA_HIP_CHECK(c, hipStreamWaitEvent(c->stream, c->ev_unpacked, 0));
     return FEAHIP_OK;
   }
   int allreduce(std::vector<feahip_ctx *> &R, int slot, int n) override

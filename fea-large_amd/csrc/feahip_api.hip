@@ -234,6 +234,7 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
   c->h_super_achunk = hp.super_achunk;
   c->h_chunk = hp.chunk;
   c->row0 = 0; c->row1 = n_nodes;
+  c->ichunk_lo = 0; c->ichunk_hi = c->nchunks;
   c->h_rowptr = hp.rowptr; c->h_colidx = hp.colidx;
   c->incslot_ok = !hp.incslot.empty();
 
@@ -267,7 +268,7 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
   if ((rc = dev_zeros(c, &c->d_p, (size_t)c->ndof))) return rc;
   if ((rc = dev_zeros(c, &c->d_q, (size_t)c->ndof))) return rc;
   if ((rc = dev_zeros(c, &c->d_minv, (size_t)c->N * 9))) return rc;
-  if ((rc = dev_zeros(c, &c->d_part, (size_t)4 * FEA_RED_BLOCKS))) return rc;
+  if ((rc = dev_zeros(c, &c->d_part, (size_t)6 * FEA_RED_BLOCKS))) return rc;
   if ((rc = dev_zeros(c, &c->d_scal, (size_t)16))) return rc;
   if ((rc = dev_zeros(c, &c->d_flag, (size_t)4))) return rc;
 
@@ -330,8 +331,11 @@ extern "C" void feahip_destroy(feahip_ctx *c)
                   c->d_dofmask, c->d_F, c->d_S};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
-  for (void *p : {(void *)c->d_send_idx, (void *)c->d_recv_idx, (void *)c->d_send_buf, (void *)c->d_recv_buf})
+  for (void *p : {(void *)c->d_send_idx, (void *)c->d_recv_idx, (void *)c->d_send_buf, (void *)c->d_recv_buf, (void *)c->d_z, (void *)c->d_w, (void *)c->d_s})
     if (p) (void)hipFree(p);
+  if (c->ev_packed) (void)hipEventDestroy(c->ev_packed);
+  if (c->ev_unpacked) (void)hipEventDestroy(c->ev_unpacked);
+  if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   if (c->tr && c->owns_tr) delete c->tr;
   amg_destroy(c);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -367,6 +371,14 @@ extern "C" int feahip_set_preconditioner(feahip_ctx *c, int kind)
   if (kind != 0 && kind != 1) { c->err = "unknown preconditioner"; return FEAHIP_EINVAL; }
   if (kind == 1) { int rc = amg_create(c); if (rc) return rc; }
   c->precond = kind;
+  return FEAHIP_OK;
+}
+
+extern "C" int feahip_set_pcg_variant(feahip_ctx *c, int variant)
+{
+  CTX_GUARD_NOK(c);
+  if (variant < -1 || variant > 1) { c->err = "unknown PCG variant"; return FEAHIP_EINVAL; }
+  c->pcg_variant = variant;
   return FEAHIP_OK;
 }
 

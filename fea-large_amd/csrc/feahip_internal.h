@@ -119,7 +119,16 @@ struct feahip_ctx {
   // vectors (3N doubles)
   double *d_f = nullptr, *d_u = nullptr;
   double *d_r = nullptr, *d_p = nullptr, *d_q = nullptr, *d_minv = nullptr;
-  double *d_part = nullptr;    // reduction partials, 4 x FEA_RED_BLOCKS
+  double *d_part = nullptr;    // reduction partials, 6 x FEA_RED_BLOCKS
+  // single-reduction PCG (kernels_solve.hip): preconditioned residual z = M r and w = K z (allocated on first use);
+  // pcg_variant: -1 = single-reduction when sharded, the reference-shaped two-reduction loop otherwise; 0 / 1 force
+  double *d_z = nullptr, *d_w = nullptr, *d_s = nullptr;
+  int pcg_variant = -1;
+  // SpMV chunks [chunk0 + ichunk_lo, chunk0 + ichunk_hi) of this rank touch no halo column: they run while the halo
+  // rows are in flight (everything, for an unsharded context)
+  int ichunk_lo = 0, ichunk_hi = 0;
+  hipStream_t comm_stream = nullptr;   // RCCL transport: halo exchange beside the interior product
+  hipEvent_t ev_packed = nullptr, ev_unpacked = nullptr;
   double *d_scal = nullptr;    // device scalars of the CG recurrences
   int *d_flag = nullptr;       // [0] converged-at iteration, [1] bad Gauss pts
   // prescribed displacements
@@ -397,8 +406,12 @@ void build_shard_plan(const std::vector<int> &rowptr, const std::vector<int> &co
 // in-process group.
 struct Transport {
   virtual ~Transport() {}
-  // halo rows of vector `which` (0 = p, 1 = u, 2 = x) from their owners
+  // halo rows of vector `which` (0 = p, 1 = u, 2 = x, 3 = z) from their owners
   virtual int exchange(std::vector<feahip_ctx *> &R, int which) = 0;
+  // the same in two halves: begin() leaves the exchange running (on a stream of its own where the transport has
+  // one), end() makes the context's stream wait for the halo rows.  Work enqueued between the two must not read them.
+  virtual int exchange_begin(std::vector<feahip_ctx *> &R, int which) { return exchange(R, which); }
+  virtual int exchange_end(std::vector<feahip_ctx *> &R) { (void)R; return FEAHIP_OK; }
   // d_scal[8+slot .. 8+slot+n) summed over all ranks, result on every rank
   virtual int allreduce(std::vector<feahip_ctx *> &R, int slot, int n) = 0;
 };

@@ -538,6 +538,99 @@ void k_cg_direction(int a0, int a1, int it, int nparts, const double *r, const d
   }
 }
 
+// ------------------------------------------------------------------------
+// single-reduction PCG (Chronopoulos / Gear form of the same recurrence).  Vectors: x, r, z = M r, w = K z,
+// p = z + beta p, s = w + beta s (= K p).  Sums of an iteration: gamma = r.z, delta = w.z, rr = r.r -- formed
+// together, one all-reduce.  Device scalars: [0],[1] gamma ping-pong, [5],[6] alpha ping-pong, [2] b.b, [3] last r.r,
+// [4] tolerance^2; gred = {gamma, delta, rr} of the state the iteration starts from (reduced over all ranks).
+// Partial sums in d_part: [0..RB) delta (rows that touch no halo column), [RB..2RB) gamma, [2RB..3RB) rr,
+// [3RB..4RB) b.b at the start, then delta of the rows in front of the interior range, [4RB..5RB) delta behind it.
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_cgcg_update(int a0, int a1, int it, const double *z, const double *w, const double *minv, double *p, double *s,
+                   double *x, double *r, double *znew, double *part, const double *gred, double *scal, int *flag)
+{
+  __shared__ double scratch[5];
+  if (flag[0] != 0) return;
+  const double gamma = gred[0], delta = gred[1], rr = gred[2];
+  const bool stop = rr <= scal[4] * scal[2];
+  double beta = 0.0, alpha = 0.0;
+  bool broke = !(gamma == gamma) || !(delta == delta) || !(rr == rr);
+  if (!stop && !broke) {
+    if (it == 0) alpha = gamma / delta;
+    else {
+      const double gamma_old = scal[(it + 1) & 1], alpha_old = scal[5 + ((it + 1) & 1)];
+      beta = gamma / gamma_old;
+      alpha = gamma / (delta - beta * gamma / alpha_old);
+    }
+    broke = !(alpha == alpha) || !(beta == beta) || alpha == 0.0;
+  }
+  double sg = 0, srr = 0;
+  if (!stop && !broke) {
+    for (int a = a0 + blockIdx.x * 256 + threadIdx.x; a < a1; a += gridDim.x * 256) {
+      const double *m = minv + (size_t)a * 9;
+      double rv[3];
+      for (int i = 0; i < 3; ++i) {
+        const size_t k = (size_t)a * 3 + i;
+        const double pk = z[k] + beta * p[k], sk = w[k] + beta * s[k];
+        p[k] = pk; s[k] = sk;
+        x[k] += alpha * pk;
+        rv[i] = r[k] - alpha * sk;
+        r[k] = rv[i];
+      }
+      for (int i = 0; i < 3; ++i) {
+        srr += rv[i] * rv[i];
+        if (minv) {                                   // block-Jacobi: z = M r here; multigrid: the cycle follows
+          const double zz = m[3 * i] * rv[0] + m[3 * i + 1] * rv[1] + m[3 * i + 2] * rv[2];
+          znew[(size_t)a * 3 + i] = zz;
+          sg += rv[i] * zz;
+        }
+      }
+    }
+  }
+  sg = block_sum(sg, scratch); srr = block_sum(srr, scratch);
+  if (threadIdx.x == 0) { part[RB + blockIdx.x] = sg; part[2 * RB + blockIdx.x] = srr; }
+  // the scalars of this iteration go to the other ping-pong slots; the flag is read at kernel entry only
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    scal[it & 1] = gamma; scal[5 + (it & 1)] = alpha; scal[3] = rr;
+    if (broke) flag[0] = -(it + 1);
+    else if (stop) flag[0] = it > 0 ? it : -1000000000;
+  }
+}
+
+// znew = z (the multigrid cycle's result) on the owned rows, partial sums of r.z
+__global__ __launch_bounds__(256)
+void k_copy_dot(int i0, int i1, const double *z, const double *r, double *znew, double *part, const int *flag)
+{
+  __shared__ double scratch[5];
+  if (flag && flag[0] != 0) return;
+  double v = 0;
+  for (int i = i0 + blockIdx.x * 256 + threadIdx.x; i < i1; i += gridDim.x * 256) { const double zi = z[i]; znew[i] = zi; v += r[i] * zi; }
+  v = block_sum(v, scratch);
+  if (threadIdx.x == 0) part[blockIdx.x] = v;
+}
+
+// out = { sum gamma partials, sum of the three delta partial ranges, sum rr partials [, sum bb partials] } (one block, fixed order)
+__global__ __launch_bounds__(256)
+void k_cgcg_reduce(int gv, int g_int, int g_pre, int g_suf, int with_bb, const double *part, double *out)
+{
+  __shared__ double scratch[5];
+  const double g = reduce_partials(part + RB, gv, scratch);
+  double d = reduce_partials(part, g_int, scratch);
+  if (g_pre > 0) d += reduce_partials(part + (with_bb ? 5 : 3) * RB, g_pre, scratch);
+  if (g_suf > 0) d += reduce_partials(part + 4 * RB, g_suf, scratch);
+  const double rr = reduce_partials(part + 2 * RB, gv, scratch);
+  const double bb = with_bb ? reduce_partials(part + 3 * RB, gv, scratch) : 0.0;
+  if (threadIdx.x == 0) { out[0] = g; out[1] = d; out[2] = rr; if (with_bb) out[3] = bb; }
+}
+
+__global__ void k_cgcg_scalars0(const double *gred, double *scal, double tol, int *flag)
+{
+  if (threadIdx.x || blockIdx.x) return;
+  scal[2] = gred[3]; scal[3] = gred[2]; scal[4] = tol * tol;
+  flag[0] = (gred[2] <= tol * tol * gred[3] || gred[0] == 0.0) ? -1000000000 : 0;   // a zero right-hand side (or an exact start vector) is already solved
+}
+
 // halo rows of a 3N vector: buf[3i+j] = v[3 idx[i] + j] and back
 __global__ void k_halo_pack(int n, const int *idx, const double *v, int vstride, double *buf)
 {
@@ -584,7 +677,7 @@ static void enq_spmv_dot(feahip_ctx *c, const double *xv, double *yv, const doub
 static double *halo_vec(feahip_ctx *c, int which, int &stride)
 {
   stride = (which == 2) ? 4 : 3;
-  return which == 0 ? c->d_p : (which == 1 ? c->d_u : c->d_x);
+  return which == 0 ? c->d_p : (which == 1 ? c->d_u : (which == 2 ? c->d_x : c->d_z));
 }
 
 static void enq_pack(feahip_ctx *c, int which)
@@ -608,6 +701,12 @@ void feahip_enq_pack(feahip_ctx *c, double *v, int stride)
   if (c->nsend <= 0) return;
   hipLaunchKernelGGL(k_halo_pack, dim3((c->nsend * 3 + 255) / 256), dim3(256), 0, c->stream, c->nsend,
                      c->d_send_idx, v, stride, c->d_send_buf);
+}
+void feahip_enq_unpack_on(feahip_ctx *c, double *v, int stride, hipStream_t stream)
+{
+  if (c->nrecv <= 0) return;
+  hipLaunchKernelGGL(k_halo_unpack, dim3((c->nrecv * 3 + 255) / 256), dim3(256), 0, stream, c->nrecv,
+                     c->d_recv_idx, c->d_recv_buf, stride, v);
 }
 void feahip_enq_unpack(feahip_ctx *c, double *v, int stride)
 {
@@ -732,6 +831,122 @@ static int enq_cg_start(std::vector<feahip_ctx *> &R, Transport *T, int mode, do
   return FEAHIP_OK;
 }
 
+// ---- single-reduction variant ------------------------------------------------
+static int ensure_cgcg(feahip_ctx *c)
+{
+  if (!c->d_z) {
+    FEA_HIP_CHECK(c, hipMalloc((void **)&c->d_z, sizeof(double) * (size_t)c->ndof));
+    FEA_HIP_CHECK(c, hipMemsetAsync(c->d_z, 0, sizeof(double) * (size_t)c->ndof, c->stream));
+  }
+  if (!c->d_w) {
+    FEA_HIP_CHECK(c, hipMalloc((void **)&c->d_w, sizeof(double) * (size_t)c->ndof));
+    FEA_HIP_CHECK(c, hipMemsetAsync(c->d_w, 0, sizeof(double) * (size_t)c->ndof, c->stream));
+  }
+  if (!c->d_s) {                                     // s = K p by recurrence (q stays the multigrid cycle's level-0 scratch)
+    FEA_HIP_CHECK(c, hipMalloc((void **)&c->d_s, sizeof(double) * (size_t)c->ndof));
+    FEA_HIP_CHECK(c, hipMemsetAsync(c->d_s, 0, sizeof(double) * (size_t)c->ndof, c->stream));
+  }
+  return FEAHIP_OK;
+}
+
+static int spmv_grid_n(int nchunks)
+{
+  int g = (nchunks + FEA_WAVES_PER_WG - 1) / FEA_WAVES_PER_WG;
+  return g < FEA_RED_BLOCKS ? (g > 0 ? g : 1) : FEA_RED_BLOCKS;
+}
+
+// w = K z with the partial sums of w.z, in three launches: the chunks that touch no halo column (they may run while
+// the halo rows of z travel: between exchange_begin and exchange_end), then the chunks in front of and behind them
+static void enq_spmv_interior(feahip_ctx *c, const double *zv, double *wv)
+{
+  const int n = c->ichunk_hi - c->ichunk_lo;
+  if (n > 0)
+    hipLaunchKernelGGL(k_spmv, dim3(spmv_grid_n(n)), dim3(256), 0, c->stream, c->chunk0 + c->ichunk_lo, n, c->d_chunk,
+                       c->d_rowptr, c->d_colidx, c->d_K, zv, wv, zv, c->d_part, (const int *)c->d_flag);
+}
+static void enq_spmv_boundary(feahip_ctx *c, const double *zv, double *wv, int pre_slot)
+{
+  const int npre = c->ichunk_lo, nsuf = c->nchunks_local - c->ichunk_hi;
+  if (npre > 0)
+    hipLaunchKernelGGL(k_spmv, dim3(spmv_grid_n(npre)), dim3(256), 0, c->stream, c->chunk0, npre, c->d_chunk,
+                       c->d_rowptr, c->d_colidx, c->d_K, zv, wv, zv, c->d_part + (size_t)pre_slot * RB, (const int *)c->d_flag);
+  if (nsuf > 0)
+    hipLaunchKernelGGL(k_spmv, dim3(spmv_grid_n(nsuf)), dim3(256), 0, c->stream, c->chunk0 + c->ichunk_hi, nsuf, c->d_chunk,
+                       c->d_rowptr, c->d_colidx, c->d_K, zv, wv, zv, c->d_part + (size_t)4 * RB, (const int *)c->d_flag);
+}
+static void enq_cgcg_reduce(feahip_ctx *c, int with_bb)
+{
+  const int n_int = c->ichunk_hi - c->ichunk_lo, npre = c->ichunk_lo, nsuf = c->nchunks_local - c->ichunk_hi;
+  hipLaunchKernelGGL(k_cgcg_reduce, dim3(1), dim3(256), 0, c->stream, vgrid(c), n_int > 0 ? spmv_grid_n(n_int) : 0,
+                     npre > 0 ? spmv_grid_n(npre) : 0, nsuf > 0 ? spmv_grid_n(nsuf) : 0, with_bb, c->d_part, c->d_scal + 8);
+}
+
+static int enq_cgcg_start(std::vector<feahip_ctx *> &R, Transport *T, int mode, double tol)
+{
+  int rc;
+  FOR_RANKS(c) {
+    if ((rc = ensure_cgcg(c))) return rc;
+    if (use_amg(c, mode)) { if ((rc = amg_prepare(c))) return rc; }
+    else enq_precond(c, mode);
+    FEA_HIP_CHECK(c, hipMemcpyAsync(c->d_u, c->d_f, sizeof(double) * (size_t)c->ndof, hipMemcpyDeviceToDevice, c->stream));
+    FEA_HIP_CHECK(c, hipMemsetAsync(c->d_p, 0, sizeof(double) * (size_t)c->ndof, c->stream));     // p = s = 0: the first iteration has beta = 0
+    FEA_HIP_CHECK(c, hipMemsetAsync(c->d_s, 0, sizeof(double) * (size_t)c->ndof, c->stream));
+  }
+  if (T && (rc = T->exchange(R, 1))) return rc;                  // halo rows of u0 = f
+  FOR_RANKS(c) {
+    const int gv = vgrid(c);
+    const bool amg = use_amg(c, mode);
+    enq_spmv_dot(c, c->d_u, c->d_w, nullptr, nullptr);           // K x0 (into w, overwritten below)
+    // r = b - K x0, z = M r, partial sums r.z, r.r, b.b
+    hipLaunchKernelGGL(k_cg_init, dim3(gv), dim3(256), 0, c->stream, own0(c), own1(c), c->d_f, c->d_w,
+                       amg ? (const double *)nullptr : c->d_minv, c->d_r, c->d_z, c->d_part);
+    if (amg) {
+      const double *z = amg_apply(c, c->d_r);
+      hipLaunchKernelGGL(k_copy_dot, dim3(gv), dim3(256), 0, c->stream, 3 * own0(c), 3 * own1(c), z, c->d_r, c->d_z, c->d_part + RB, (const int *)nullptr);
+    }
+  }
+  if (T && (rc = T->exchange_begin(R, 3))) return rc;            // halo rows of z
+  FOR_RANKS(c) enq_spmv_interior(c, c->d_z, c->d_w);
+  if (T && (rc = T->exchange_end(R))) return rc;
+  FOR_RANKS(c) {
+    enq_spmv_boundary(c, c->d_z, c->d_w, 5);                     // (slot 3 holds b.b at the start)
+    enq_cgcg_reduce(c, 1);
+  }
+  if (T && (rc = T->allreduce(R, 0, 4))) return rc;              // gamma, delta, rr, bb
+  FOR_RANKS(c) {
+    hipLaunchKernelGGL(k_cgcg_scalars0, dim3(1), dim3(1), 0, c->stream, c->d_scal + 8, c->d_scal, tol, c->d_flag);
+    FEA_HIP_CHECK(c, hipGetLastError());
+  }
+  return FEAHIP_OK;
+}
+
+static int enq_cgcg_iteration(std::vector<feahip_ctx *> &R, Transport *T, int it, int mode)
+{
+  int rc;
+  FOR_RANKS(c) {
+    const int gv = vgrid(c);
+    const bool amg = use_amg(c, mode);
+    hipLaunchKernelGGL(k_cgcg_update, dim3(gv), dim3(256), 0, c->stream, own0(c), own1(c), it, c->d_z, c->d_w,
+                       amg ? (const double *)nullptr : c->d_minv, c->d_p, c->d_s, c->d_u, c->d_r, c->d_z, c->d_part,
+                       c->d_scal + 8, c->d_scal, c->d_flag);
+    if (amg) {
+      const double *z = amg_apply(c, c->d_r);                      // local: block-Jacobi over the ranks, a W-cycle inside
+      hipLaunchKernelGGL(k_copy_dot, dim3(gv), dim3(256), 0, c->stream, 3 * own0(c), 3 * own1(c), z, c->d_r, c->d_z, c->d_part + RB, (const int *)c->d_flag);
+    }
+  }
+  if (T && (rc = T->exchange_begin(R, 3))) return rc;            // halo rows of z on their way ...
+  FOR_RANKS(c) enq_spmv_interior(c, c->d_z, c->d_w);             // ... under the rows that do not need them
+  if (T && (rc = T->exchange_end(R))) return rc;
+  FOR_RANKS(c) {
+    enq_spmv_boundary(c, c->d_z, c->d_w, 3);
+    enq_cgcg_reduce(c, 0);
+  }
+  if (T && (rc = T->allreduce(R, 0, 3))) return rc;              // gamma, delta, rr: the one reduction of the iteration
+  return FEAHIP_OK;
+}
+
+static inline bool use_cgcg(const feahip_ctx *c, Transport *T) { return c->pcg_variant == 1 || (c->pcg_variant < 0 && T != nullptr); }
+
 // Solves K u = f by (preconditioned) CG started from u0 = f, the start vector
 // the reference hands to sp_matrix_yale_solve_cg (fea_solver.c:251-256).
 int dist_solve_pcg(std::vector<feahip_ctx *> &R, int type, double tol, int max_iter, int *iters, double *resid)
@@ -740,14 +955,15 @@ int dist_solve_pcg(std::vector<feahip_ctx *> &R, int type, double tol, int max_i
   feahip_ctx *c0 = R[0];
   const int mode = (type == FEAHIP_CG) ? 0 : 1;
   if (type == FEAHIP_CHOLESKY) { tol = 1e-16; if (max_iter < 100000) max_iter = 100000; }
-  int rc = enq_cg_start(R, T, mode, tol);
+  const bool cgcg = use_cgcg(c0, T);
+  int rc = cgcg ? enq_cgcg_start(R, T, mode, tol) : enq_cg_start(R, T, mode, tol);
   if (rc) return rc;
   int flag = 0, it = 0;
   const int batch = use_amg(c0, mode) ? 8 : 32;
   while (it < max_iter) {
     const int n = (max_iter - it < batch) ? (max_iter - it) : batch;
     for (int k = 0; k < n; ++k)
-      if ((rc = enq_cg_iteration(R, T, it + k, mode))) return rc;
+      if ((rc = cgcg ? enq_cgcg_iteration(R, T, it + k, mode) : enq_cg_iteration(R, T, it + k, mode))) return rc;
     it += n;
     (void)hipSetDevice(c0->device);
     FEA_HIP_CHECK(c0, hipGetLastError());
@@ -847,15 +1063,16 @@ int time_pcg_iteration(feahip_ctx *c, int warmup, int iters, double *avg_ms)
   std::vector<feahip_ctx *> R(1, c);
   Transport *T = c->tr;
   int rc;
-  rc = enq_cg_start(R, T, 1, 0.0);
+  const bool cgcg = use_cgcg(c, T);
+  rc = cgcg ? enq_cgcg_start(R, T, 1, 0.0) : enq_cg_start(R, T, 1, 0.0);
   if (rc) return rc;
   FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
   hipEvent_t e0, e1;
   FEA_HIP_CHECK(c, hipEventCreate(&e0));
   FEA_HIP_CHECK(c, hipEventCreate(&e1));
-  for (int k = 0; k < warmup; ++k) if ((rc = enq_cg_iteration(R, T, k, 1))) return rc;
+  for (int k = 0; k < warmup; ++k) if ((rc = cgcg ? enq_cgcg_iteration(R, T, k, 1) : enq_cg_iteration(R, T, k, 1))) return rc;
   FEA_HIP_CHECK(c, hipEventRecord(e0, c->stream));
-  for (int k = 0; k < iters; ++k) if ((rc = enq_cg_iteration(R, T, warmup + k, 1))) return rc;
+  for (int k = 0; k < iters; ++k) if ((rc = cgcg ? enq_cgcg_iteration(R, T, warmup + k, 1) : enq_cg_iteration(R, T, warmup + k, 1))) return rc;
   FEA_HIP_CHECK(c, hipEventRecord(e1, c->stream));
   FEA_HIP_CHECK(c, hipEventSynchronize(e1));
   float ms = 0;

@@ -58,6 +58,7 @@ ABI = {
     "feahip_set_assembly": [C.c_void_p, C.c_int],
     "feahip_set_preconditioner": [C.c_void_p, C.c_int],
     "feahip_set_line_search": [C.c_void_p, C.c_int],
+    "feahip_set_pcg_variant": [C.c_void_p, C.c_int],
     "feahip_set_row_shard": [C.c_void_p, C.c_int, C.c_int],
     "feahip_comm_unique_id": [C.c_void_p, C.c_int],
     "feahip_comm_init": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
@@ -426,6 +427,9 @@ class FeaSolver:
     # ---- tuning / measurement ------------------------------------------
     def set_preconditioner(self, kind):
         self._chk(self._lib.feahip_set_preconditioner(self._ctx, kind))
+
+    def set_pcg_variant(self, variant):
+        self._chk(self._lib.feahip_set_pcg_variant(self._ctx, variant))
 
     def set_line_search(self, max_iterations):
         self._chk(self._lib.feahip_set_line_search(self._ctx, max_iterations))

@@ -266,6 +266,17 @@ int feahip_set_assembly(feahip_ctx *ctx, int strategy);
  * way the solve runs to the requested residual, so the solution is the same
  * to that tolerance.                                                          */
 int feahip_set_preconditioner(feahip_ctx *ctx, int kind);
+/* The CG / PCG loop of feahip_solve_slae.  0: the textbook loop (what the
+ * reference's sp_matrix_yale_solve_cg / _pcg_ilu run, fea_solver.c:245-280):
+ * two reductions per iteration (p.Kp, then r.z and r.r), halo rows exchanged
+ * before the product.  1: the single-reduction form of the same recurrence
+ * (Chronopoulos / Gear): p = z + beta p and s = w + beta s with w = K z kept
+ * by recurrence, so that r.z, w.z and r.r of an iteration are summed together
+ * -- ONE all-reduce of three doubles per iteration -- and the halo rows of z
+ * travel while the rows that touch no halo column are multiplied.  Same
+ * iterates in exact arithmetic; the solve runs to the same residual.  -1
+ * (default): 1 for a sharded context, 0 otherwise.                            */
+int feahip_set_pcg_variant(feahip_ctx *ctx, int variant);
 /* Line search along every Newton step of feahip_solve / feahip_group_solve:
  * golden-section search, `max_iterations` iterations, for the step length in
  * [1/2, 1] that minimises |eta <u, R(x + eta u)>| -- what the reference's

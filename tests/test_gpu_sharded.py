@@ -78,6 +78,39 @@ def test_sharded_linear_solve(n, solver):
     g.close(); one.close()
 
 
+@pytest.mark.parametrize("solver,precond", [(feahip.PCG_ILU, 0), (feahip.CG, 0), (feahip.PCG_ILU, 1)])
+def test_single_reduction_pcg_is_the_same_solve(solver, precond):
+    """feahip_set_pcg_variant: the single-reduction loop (one all-reduce of {r.z, w.z, r.r} per iteration, halo rows of
+    z in flight under the rows that touch no halo column) against the reference-shaped two-reduction loop, on one
+    context and on 2 and 3 in-process ranks, block-Jacobi, plain CG and the multigrid: the same solution to 1e-11,
+    the same iteration count within 2, the same <u,f>.  A sharded context runs the single-reduction loop by default."""
+    deck = mesh.bar_deck(dims=(6, 96, 6) if precond else (3, 48, 3))
+    ref = feahip.FeaSolver(deck)
+    ref.set_pcg_variant(0); ref.set_preconditioner(precond)
+    ref.update_nodes_with_bc(1.0); ref.create_stiffness_and_residual(); ref.apply_prescribed_bc(0.0)
+    it0, res0 = ref.solve_slae(solver, 1e-15, 20000)
+    u0, e0 = ref.solution(), ref.energy()
+    one = feahip.FeaSolver(deck)
+    one.set_pcg_variant(1); one.set_preconditioner(precond)
+    one.update_nodes_with_bc(1.0); one.create_stiffness_and_residual(); one.apply_prescribed_bc(0.0)
+    it1, res1 = one.solve_slae(solver, 1e-15, 20000)
+    assert res1 < 1e-14 and abs(it1 - it0) <= 2
+    assert rel(one.solution(), u0) < 1e-11 and one.energy() == pytest.approx(e0, rel=1e-11)
+    for n in (2, 3):
+        for variant in (-1, 0):                                    # -1: the default of a sharded context = single reduction
+            g = feahip.FeaGroup(deck, n)
+            g.each("set_pcg_variant", variant); g.each("set_preconditioner", precond)
+            g.each("update_nodes_with_bc", 1.0); g.each("create_stiffness_and_residual"); g.each("apply_prescribed_bc", 0.0)
+            itn, resn = g.solve_slae(solver, 1e-15, 20000)
+            assert resn < 1e-14
+            if not precond:                                       # (the multigrid is block-Jacobi over the ranks: another preconditioner)
+                assert abs(itn - it0) <= 2
+            assert rel(g.gather("solution"), u0) < 1e-11
+            assert g.energy() == pytest.approx(e0, rel=1e-11)
+            g.close()
+    one.close(); ref.close()
+
+
 def test_sharded_newton_matches_oracle(decks_dir):
     """The shipped clamped deck on 2 ranks: same iteration sequence as the
     oracle, displacements within 1e-10 (BASELINE.json)."""
