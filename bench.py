@@ -137,7 +137,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n", type=int, default=66, help="block of n x 6n x n cubes (66 = 10M tets, 31 = 1M)")
+    ap.add_argument("--n", "--cubes", dest="n", type=int, default=66, help="block of n x 6n x n cubes (66 = 10M tets, 31 = 1M)")
     ap.add_argument("--quadratic", action="store_true", help="TET10 / 5 Gauss points instead of TET4 / 1")
     ap.add_argument("--hex", action="store_true", help="HEXAHEDRA8 / 8 Gauss points: one trilinear brick per cube (n x 6n x n bricks)")
     ap.add_argument("--model", default="neohookean", choices=["neohookean", "a5"])
@@ -201,14 +201,18 @@ def main():
     deck = mesh.bar_deck(n=args.n, quadratic=args.quadratic, hexa=args.hex, recipe="clamped", model=model, brick=brick,
                          solver_type=feahip.PCG_ILU, solver_tolerance=1e-14, solver_max_iter=20000)
     free0 = torch.cuda.mem_get_info(local)[0]
-    solver = feahip.FeaSolver(deck, device=local)
-    solver.set_assembly(getattr(feahip, "ASM_" + args.assembly.upper()))
     comm_ok = False
     if world > 1:
-        # the timed assembly needs the row shard only (no collective); the RCCL communicator of the
-        # sharded solve is built afterwards, under the watchdog, so a wedged rendezvous cannot cost the line
-        solver.set_row_shard(rank, world)
-    solver.set_nodes(mesh.deformed_state(deck.nodes))
+        # a rank holds only its slab (feahip_create_rank): the nodes it owns, the elements around them, their halo --
+        # locally indexed; the timed assembly needs no collective; the RCCL communicator of the sharded solve is built
+        # afterwards, under the watchdog, so a wedged rendezvous cannot cost the line
+        solver = feahip.RankSolver(deck, rank, world, device=local)
+        local_nodes = solver.node_global.astype(np.int64)
+    else:
+        solver = feahip.FeaSolver(deck, device=local)
+        local_nodes = slice(None)
+    solver.set_assembly(getattr(feahip, "ASM_" + args.assembly.upper()))
+    solver.set_nodes(mesh.deformed_state(deck.nodes)[local_nodes])
     solver.create_stiffness_and_residual()              # builds the assembly maps of the rows this rank owns
     solver.sync()
     sz = solver.sizes()
@@ -219,7 +223,14 @@ def main():
               feahip.ASM_SHARED: "k_assemble_quad", feahip.ASM_PATCH: "k_assemble_patch", feahip.ASM_PAIRED: "k_assemble_pair",
               feahip.ASM_ATOMIC: "k_assemble_atomic"}.get(in_use, "k_assemble_rowowner")
 
-    E_total, N, nnz = sz["E"], sz["N"], sz["nnzb"] * 9
+    E_total, N = len(deck.elements), len(deck.nodes)
+    if world > 1:
+        # the whole matrix's non-zeros = the sum of the ranks' owned rows
+        nn = torch.tensor([solver.nnzb_owned * 9], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(nn)
+        nnz = int(nn.item())
+    else:
+        nnz = sz["nnzb"] * 9
     # The device needs ~25 back-to-back launches (~30 ms of load) to reach its sustained clocks: the rocprofv3 trace
     # of this program shows the same kernel on the same data going from 1.25 to 1.01 ms over its first 25 launches
     # (profiles/r01_l_*).  A Newton loop keeps the device busy for seconds, so the sustained rate is the
@@ -247,7 +258,7 @@ def main():
     value = E_total * args.steps / dt
 
     share = 1.0 / world
-    renumbered = not np.array_equal(solver.node_numbering(), np.arange(N))
+    renumbered = True if world > 1 else not np.array_equal(solver.node_numbering(), np.arange(N))
     # ---- one untimed cross-check of the K the timed launches assemble: its product with a random vector against the
     # product of the K a second, independent kernel assembles from the same state (staged visits / the generic
     # row-owner kernel), K . translation = 0, and symmetry by <a, K b> = <b, K a>
@@ -295,6 +306,8 @@ def main():
         "copy_bandwidth_GBps": copy_gbps,
         "assembly_frac_of_copy_bandwidth": achieved / copy_gbps if copy_gbps else None,
         "device_addresses_mod_2MiB": {k: v % (1 << 21) for k, v in solver.device_layout().items()},
+        "rank0_holds": ({"nodes": solver.N, "owned_nodes": solver.n_own, "elements": solver.E, "rows_sent_per_exchange": solver.rows_sent}
+                        if world > 1 else None),
     }
 
     # ---- the reference's own element next to the headline: 10-node tetrahedra / 5 Gauss points on a small block
@@ -329,8 +342,8 @@ def main():
                                f"({args.n}x{6 * args.n}x{args.n} {'bricks' if args.hex else 'Kuhn cubes'} on the 1x6x1 bar), "
                                f"stiffness+residual assembly, deformed state k1=1.1",
                    "elements": E_total, "nodes": N, "scalar_nnz": nnz, "clock_ramp_launches_before_warmup": RAMP,
-                   "sharding": f"block rows in {world} slab(s) across y, ghost elements recomputed, "
-                               f"no collective in assembly"},
+                   "sharding": f"{world} slab(s) across y; a rank holds only its slab (owned nodes, the elements around them, their halo, "
+                               f"locally indexed); ghost elements recomputed, no collective in assembly"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": kernel, "algorithmic_bytes_per_launch": B},
@@ -369,7 +382,6 @@ def main():
             except Exception as e:                  # noqa: BLE001
                 why = f"rccl init failed on rank {rank}: {e}"
                 print(f"[rank {rank}] {why}", file=sys.stderr)
-                solver.set_row_shard(rank, world)
         flags = [None] * world
         dist.all_gather_object(flags, (comm_ok, why))
         comm_ok = all(f[0] for f in flags)
@@ -384,7 +396,7 @@ def main():
             if not args.no_newton:
                 # one full Newton iteration of the first load increment: bump, assemble, BC, PCG to 1e-14, update
                 def newton_iteration():
-                    solver.set_nodes(deck.nodes)
+                    solver.set_nodes(deck.nodes[local_nodes])
                     solver.sync(); barrier()
                     t0 = time.perf_counter()
                     solver.update_nodes_with_bc(1.0)

@@ -12,24 +12,12 @@
 #include <cmath>
 #include <cstring>
 
-int install_shard(feahip_ctx *c, int rank, int nranks)
+// halo lists of a plan to the device, and the longest run of this rank's SpMV chunks whose rows touch no halo column:
+// they can be multiplied while the halo rows are in flight (a slab has its halo-touching chunks at its two ends)
+int install_plan(feahip_ctx *c, const ShardPlan &plan)
 {
-  if (nranks < 1 || rank < 0 || rank >= nranks) { c->err = "bad shard (rank, nranks)"; return FEAHIP_EINVAL; }
-  const int nsuper = (c->nchunks + FEA_SUPER_CHUNKS - 1) / FEA_SUPER_CHUNKS;
-  const int s0 = (int)((long long)nsuper * rank / nranks), s1 = (int)((long long)nsuper * (rank + 1) / nranks);
-  c->chunk0 = s0 * FEA_SUPER_CHUNKS < c->nchunks ? s0 * FEA_SUPER_CHUNKS : c->nchunks;
-  c->nchunks_local = (s1 * FEA_SUPER_CHUNKS < c->nchunks ? s1 * FEA_SUPER_CHUNKS : c->nchunks) - c->chunk0;
-  if (!c->h_super_achunk.empty()) {
-    c->achunk0 = c->h_super_achunk[s0];
-    c->nachunks_local = c->h_super_achunk[s1] - c->achunk0;
-  }
-  ShardPlan plan;
-  build_shard_plan(c->h_rowptr, c->h_colidx, c->h_chunk, rank, nranks, plan);
-  if (plan.row0 != c->row0 || plan.row1 != c->row1) release_k(c);     // K is re-allocated for the new rows on next use
-  c->rank = rank; c->nranks = nranks; c->row0 = plan.row0; c->row1 = plan.row1;
+  c->rank = plan.rank; c->nranks = plan.nranks; c->row0 = plan.row0; c->row1 = plan.row1;
   {
-    // the longest run of this rank's SpMV chunks whose rows touch no halo column: they can be multiplied while the
-    // halo rows are in flight (a slab has its halo-touching chunks at its two ends)
     int best_lo = 0, best_hi = 0, lo = -1;
     for (int k = 0; k <= c->nchunks_local; ++k) {
       bool interior = false;
@@ -60,6 +48,28 @@ int install_shard(feahip_ctx *c, int rank, int nranks)
   FEA_HIP_CHECK(c, hipMalloc((void **)&c->d_send_buf, sizeof(double) * 3 * (size_t)(c->nsend ? c->nsend : 1)));
   FEA_HIP_CHECK(c, hipMalloc((void **)&c->d_recv_buf, sizeof(double) * 3 * (size_t)(c->nrecv ? c->nrecv : 1)));
   return FEAHIP_OK;
+}
+
+int install_shard(feahip_ctx *c, int rank, int nranks)
+{
+  if (nranks < 1 || rank < 0 || rank >= nranks) { c->err = "bad shard (rank, nranks)"; return FEAHIP_EINVAL; }
+  if (c->rank_own >= 0) {                                     // a rank context is its shard: nothing to cut
+    if (rank == c->rank && nranks == c->nranks) return FEAHIP_OK;
+    c->err = "a rank context (feahip_create_rank) holds one rank's sub-mesh and cannot be re-sharded";
+    return FEAHIP_EINVAL;
+  }
+  const int nsuper = (c->nchunks + FEA_SUPER_CHUNKS - 1) / FEA_SUPER_CHUNKS;
+  const int s0 = (int)((long long)nsuper * rank / nranks), s1 = (int)((long long)nsuper * (rank + 1) / nranks);
+  c->chunk0 = s0 * FEA_SUPER_CHUNKS < c->nchunks ? s0 * FEA_SUPER_CHUNKS : c->nchunks;
+  c->nchunks_local = (s1 * FEA_SUPER_CHUNKS < c->nchunks ? s1 * FEA_SUPER_CHUNKS : c->nchunks) - c->chunk0;
+  if (!c->h_super_achunk.empty()) {
+    c->achunk0 = c->h_super_achunk[s0];
+    c->nachunks_local = c->h_super_achunk[s1] - c->achunk0;
+  }
+  ShardPlan plan;
+  build_shard_plan(c->h_rowptr, c->h_colidx, c->h_chunk, rank, nranks, plan);
+  if (plan.row0 != c->row0 || plan.row1 != c->row1) release_k(c);     // K is re-allocated for the new rows on next use
+  return install_plan(c, plan);
 }
 
 // ---- RCCL ------------------------------------------------------------------

@@ -183,7 +183,7 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
         return FEAHIP_EINVAL;
       }
     const char *e = getenv("FEAHIP_RENUMBER");
-    if (!(e && atoi(e) == 0) && locality_numbering(n_nodes, n_elems, npe, elements, nodes0, c->perm)) {
+    if (c->rank_own < 0 && !(e && atoi(e) == 0) && locality_numbering(n_nodes, n_elems, npe, elements, nodes0, c->perm)) {
       bool identity = true;
       for (int a = 0; a < n_nodes && identity; ++a) identity = c->perm[a] == a;
       if (identity) c->perm.clear();
@@ -224,7 +224,7 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
   // pattern + incidence maps (host, once)
   c->h_pat = new HostPattern();
   HostPattern &hp = *c->h_pat;
-  if ((rc = build_host_pattern(n_nodes, n_elems, npe, elements, hp, c->err))) return rc;
+  if ((rc = build_host_pattern(n_nodes, n_elems, npe, elements, hp, c->err, c->rank_own))) return rc;    // (a rank context: chunks break at its first halo row)
   c->nnzb = (int)hp.colidx.size();
   c->max_rowlen = hp.max_rowlen;
   c->nchunks = (int)hp.chunk.size() - 1;
@@ -233,6 +233,10 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
   c->achunk0 = 0; c->nachunks_local = c->nachunks;
   c->h_super_achunk = hp.super_achunk;
   c->h_chunk = hp.chunk;
+  if (c->rank_own >= 0) {                                   // a rank context: the chunks of the rows it owns
+    c->nchunks_local = hp.break_chunk;
+    if (!hp.super_achunk.empty()) c->nachunks_local = hp.super_achunk[hp.break_super];
+  }
   c->row0 = 0; c->row1 = n_nodes;
   c->ichunk_lo = 0; c->ichunk_hi = c->nchunks;
   c->h_rowptr = hp.rowptr; c->h_colidx = hp.colidx;
@@ -316,6 +320,104 @@ extern "C" int feahip_create(feahip_ctx **out, int device, int n_nodes, int n_el
     return rc;
   }
   *out = c;
+  return FEAHIP_OK;
+}
+
+// One rank's context of a sharded run: the sub-mesh of rankmesh.cpp as an ordinary context -- locally indexed, rows
+// [0, n_own) owned, the halo plan installed -- so that nothing on a rank is sized by the whole mesh.
+extern "C" int feahip_create_rank(feahip_ctx **out, int device, int rank, int nranks, int n_nodes, int n_elems, int npe,
+                                  int gauss_count, const double *gauss_weights, const double *dforms,
+                                  const int *elements, const double *nodes0, int model,
+                                  const double *model_params, int params_count, int n_presc,
+                                  const int *presc_node, const int *presc_type, const double *presc_values)
+{
+  if (!out) { g_create_error = "null output pointer"; return FEAHIP_EINVAL; }
+  *out = nullptr;
+  if (n_nodes <= 0 || n_elems <= 0 || !elements || !nodes0 || (npe != 4 && npe != 8 && npe != 10) ||
+      n_presc < 0 || (n_presc > 0 && (!presc_node || !presc_type || !presc_values))) {
+    g_create_error = "feahip_create_rank: null or empty input"; return FEAHIP_EINVAL;
+  }
+  RankMesh rm;
+  int rc = build_rank_mesh(rank, nranks, n_nodes, n_elems, npe, elements, nodes0, n_presc, presc_node, presc_type, presc_values, rm, g_create_error);
+  if (rc) return rc;
+  if (rm.elem_global.empty() || rm.n_own <= 0) { g_create_error = "this rank owns no node of the mesh (more ranks than slabs)"; return FEAHIP_EINVAL; }
+  feahip_ctx *c = new (std::nothrow) feahip_ctx();
+  if (!c) { g_create_error = "out of host memory"; return FEAHIP_ENOMEM; }
+  c->rank_own = rm.n_own;
+  rc = create_impl(c, device, (int)rm.node_global.size(), (int)rm.elem_global.size(), npe, gauss_count, gauss_weights, dforms,
+                   rm.elements.data(), rm.nodes0.data(), model, model_params, params_count, (int)rm.presc_node.size(),
+                   rm.presc_node.data(), rm.presc_type.data(), rm.presc_values.data());
+  if (rc == FEAHIP_OK) {
+    rc = install_plan(c, rm.plan);                         // rows [0, n_own), peers, halo lists, interior chunk range
+  }
+  if (rc != FEAHIP_OK) { g_create_error = c->err; feahip_destroy(c); return rc; }
+  c->rank_node_global = rm.node_global; c->rank_elem_global = rm.elem_global; c->rank_n_global = n_nodes;
+  *out = c;
+  return FEAHIP_OK;
+}
+
+extern "C" int feahip_rank_counts(feahip_ctx *c, long long *o)
+{
+  if (!c || !o || c->rank_own < 0) return FEAHIP_EINVAL;
+  o[0] = c->N; o[1] = c->rank_own; o[2] = c->E; o[3] = c->rank_n_global; o[4] = c->nnzb;
+  o[5] = (long long)c->h_rowptr[c->rank_own]; o[6] = c->nsend; o[7] = c->nrecv;
+  return FEAHIP_OK;
+}
+
+extern "C" int feahip_rank_maps(feahip_ctx *c, int *node_global, int *elem_global)
+{
+  if (!c || c->rank_own < 0) return FEAHIP_EINVAL;
+  if (node_global) std::copy(c->rank_node_global.begin(), c->rank_node_global.end(), node_global);
+  if (elem_global) std::copy(c->rank_elem_global.begin(), c->rank_elem_global.end(), elem_global);
+  return FEAHIP_OK;
+}
+
+// Host-only (no device): what rank `rank` of `nranks` would hold -- counts[8] = {local nodes, owned nodes, local
+// elements, blocks of the owned rows, blocks of all local rows, peers, rows sent, rows received}; with non-null arrays
+// (sized by a first call) the local nodes' caller ids, the local elements' caller indices, and the block rows of the
+// OWNED nodes as built from the rank's own elements (rowptr[owned + 1], column = CALLER id of the column node).
+extern "C" int feahip_host_rank_mesh(int rank, int nranks, int n_nodes, int n_elems, int npe, const int *elements,
+                                     const double *nodes0, long long *counts, int *node_global, int *elem_global,
+                                     long long *rowptr, int *colidx)
+{
+  if (!elements || !nodes0 || !counts || n_nodes <= 0 || n_elems <= 0) return FEAHIP_EINVAL;
+  RankMesh rm;
+  std::string err;
+  int rc = build_rank_mesh(rank, nranks, n_nodes, n_elems, npe, elements, nodes0, 0, nullptr, nullptr, nullptr, rm, err);
+  if (rc) return rc;
+  HostPattern hp;
+  const int nl = (int)rm.node_global.size();
+  if ((rc = build_host_pattern(nl, (int)rm.elem_global.size(), npe, rm.elements.data(), hp, err, rm.n_own))) return rc;
+  counts[0] = nl; counts[1] = rm.n_own; counts[2] = (long long)rm.elem_global.size();
+  counts[3] = hp.rowptr[rm.n_own]; counts[4] = (long long)hp.colidx.size();
+  counts[5] = (long long)rm.plan.peer.size(); counts[6] = (long long)rm.plan.send_idx.size(); counts[7] = (long long)rm.plan.recv_idx.size();
+  if (node_global) std::copy(rm.node_global.begin(), rm.node_global.end(), node_global);
+  if (elem_global) std::copy(rm.elem_global.begin(), rm.elem_global.end(), elem_global);
+  if (rowptr && colidx) {
+    for (int a = 0; a <= rm.n_own; ++a) rowptr[a] = hp.rowptr[a];
+    for (int q = 0; q < hp.rowptr[rm.n_own]; ++q) colidx[q] = rm.node_global[hp.colidx[q]];
+  }
+  return FEAHIP_OK;
+}
+
+// Host-only: the halo plan of one rank's sub-mesh in the CALLER's node ids (counts[3] = {peers, rows sent, rows received}
+// by a first call with null lists): what it sends to and receives from every peer, in the order the rows travel.
+extern "C" int feahip_host_rank_plan(int rank, int nranks, int n_nodes, int n_elems, int npe, const int *elements,
+                                     const double *nodes0, int *counts, int *peers, int *send_off, int *recv_off,
+                                     int *send_idx, int *recv_idx)
+{
+  if (!elements || !nodes0 || !counts || n_nodes <= 0 || n_elems <= 0) return FEAHIP_EINVAL;
+  RankMesh rm;
+  std::string err;
+  int rc = build_rank_mesh(rank, nranks, n_nodes, n_elems, npe, elements, nodes0, 0, nullptr, nullptr, nullptr, rm, err);
+  if (rc) return rc;
+  const ShardPlan &pl = rm.plan;
+  counts[0] = (int)pl.peer.size(); counts[1] = (int)pl.send_idx.size(); counts[2] = (int)pl.recv_idx.size();
+  if (peers) std::copy(pl.peer.begin(), pl.peer.end(), peers);
+  if (send_off) std::copy(pl.send_off.begin(), pl.send_off.end(), send_off);
+  if (recv_off) std::copy(pl.recv_off.begin(), pl.recv_off.end(), recv_off);
+  if (send_idx) for (size_t i = 0; i < pl.send_idx.size(); ++i) send_idx[i] = rm.node_global[pl.send_idx[i]];
+  if (recv_idx) for (size_t i = 0; i < pl.recv_idx.size(); ++i) recv_idx[i] = rm.node_global[pl.recv_idx[i]];
   return FEAHIP_OK;
 }
 

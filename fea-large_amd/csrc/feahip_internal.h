@@ -157,6 +157,11 @@ struct feahip_ctx {
   // library-side node numbering (renumber.cpp): everything in the context -- mesh arrays, pattern, K, vectors, shard
   // ranges -- lives in the library's numbering; the ABI translates at its boundary.  Empty = the caller's numbering.
   std::vector<int> perm, iperm;        // perm[caller id] = library id, iperm = its inverse
+  // a rank context (feahip_create_rank): this context IS one rank's sub-mesh, locally indexed; its "caller ids" are the
+  // local ids, rank_node_global / rank_elem_global say which nodes and elements of the whole mesh they are
+  int rank_own = -1;                   // nodes it owns (local ids [0, rank_own)); -1: an ordinary context
+  std::vector<int> rank_node_global, rank_elem_global;
+  int rank_n_global = 0;
 
   // preconditioner of PCG_ILU / CHOLESKY solves: 0 = 3x3 block-Jacobi, 1 = aggregation multigrid (amg.h)
   // which matrix d_K holds: bumped by every stiffness assembly, copied by stash / restore; k_bc = prescribed-dof
@@ -191,9 +196,10 @@ struct HostPattern {
   std::vector<int> achunk;               // assembly partition of the staged kernel (4-node elements)
   std::vector<int> super_achunk;         // first achunk of every super, [nsuper+1]
   int max_rowlen = 0;
+  int break_chunk = 0, break_super = 0;  // first chunk / super at or behind row_break (their counts when there is no break)
 };
 int build_host_pattern(int N, int E, int npe, const int *conn, HostPattern &hp,
-                       std::string &err);
+                       std::string &err, int row_break = -1);
 
 // patches.cpp -- per-chunk maps of the PATCH assembly (kernels_patch.hip)
 #define FEA_PATCH_MAX_NODES 128      // unique nodes touched by one patch (LDS coordinate tile)
@@ -400,6 +406,25 @@ struct ShardPlan {
 void shard_row_range(const std::vector<int> &chunk, int rank, int nranks, int &row0, int &row1);
 void build_shard_plan(const std::vector<int> &rowptr, const std::vector<int> &colidx,
                       const std::vector<int> &chunk, int rank, int nranks, ShardPlan &plan);
+
+// rankmesh.cpp -- the sub-mesh one rank of a sharded run holds, locally indexed (owned nodes first, then halo)
+struct RankMesh {
+  int rank = 0, nranks = 1, npe = 0;
+  int n_global = 0, n_own = 0;          // nodes of the whole mesh; nodes this rank owns (local ids [0, n_own))
+  int lib0 = 0, lib1 = 0;               // the library ids it owns
+  std::vector<int> node_global, node_lib;   // per local node: the caller's id, the library id
+  std::vector<int> elem_global;         // per local element: the caller's element index
+  std::vector<int> elements;            // [local elements][npe] local node ids
+  std::vector<double> nodes0;           // [local nodes][3]
+  std::vector<int> presc_node, presc_type;
+  std::vector<double> presc_values;
+  ShardPlan plan;                       // halo plan in local ids
+};
+void rank_row_range(int N, int npe, int rank, int nranks, int &g0, int &g1);
+int build_rank_mesh(int rank, int nranks, int N, int E, int npe, const int *elements, const double *nodes0,
+                    int n_presc, const int *presc_node, const int *presc_type, const double *presc_values,
+                    RankMesh &out, std::string &err);
+int install_plan(feahip_ctx *c, const ShardPlan &plan);      // dist.hip: halo lists to the device, interior chunk range
 
 // multi-rank operations (kernels_solve.hip).  R = the ranks driven by this
 // process: one context with the RCCL transport, or all contexts of an

@@ -10,6 +10,7 @@
 #include "feahip_internal.h"
 #include <algorithm>
 #include <thread>
+#include <utility>
 
 namespace {
 
@@ -31,7 +32,7 @@ void parallel_ranges(int n, F f)
 }  // namespace
 
 int build_host_pattern(int N, int E, int npe, const int *conn, HostPattern &hp,
-                       std::string &err)
+                       std::string &err, int row_break)
 {
   if (E >= (1 << 28)) { err = "too many elements for the packed incidence word"; return FEAHIP_EINVAL; }
   for (long long i = 0; i < (long long)E * npe; ++i)
@@ -95,7 +96,9 @@ int build_host_pattern(int N, int E, int npe, const int *conn, HostPattern &hp,
   int rows = 0, blocks = 0;
   for (int a = 0; a < N; ++a) {
     int len = hp.rowptr[a + 1] - hp.rowptr[a];
-    if (rows > 0 && (rows == FEA_CHUNK_ROWS || blocks + len > FEA_CHUNK_BLOCKS)) {
+    // row_break (a rank's sub-mesh: its first halo row): chunks, supers and assembly chunks break there, so that
+    // "the rows this rank owns" is a whole number of each
+    if (rows > 0 && (rows == FEA_CHUNK_ROWS || blocks + len > FEA_CHUNK_BLOCKS || a == row_break)) {
       hp.chunk.push_back(a);
       rows = 0; blocks = 0;
     }
@@ -103,6 +106,18 @@ int build_host_pattern(int N, int E, int npe, const int *conn, HostPattern &hp,
   }
   hp.chunk.push_back(N);
   const int nchunks = (int)hp.chunk.size() - 1;
+  hp.break_chunk = nchunks;
+  if (row_break > 0 && row_break < N)
+    hp.break_chunk = (int)(std::lower_bound(hp.chunk.begin(), hp.chunk.end(), row_break) - hp.chunk.begin());
+  // supers: FEA_SUPER_CHUNKS chunks each, a new one at the break
+  std::vector<std::pair<int, int>> supers;
+  for (int part = 0; part < 2; ++part) {
+    const int lo = part ? hp.break_chunk : 0, hi = part ? nchunks : hp.break_chunk;
+    for (int s0 = lo; s0 < hi; s0 += FEA_SUPER_CHUNKS) supers.emplace_back(s0, std::min(hi, s0 + FEA_SUPER_CHUNKS));
+  }
+  hp.break_super = (int)supers.size();
+  for (size_t k = 0; k < supers.size(); ++k)
+    if (supers[k].first >= hp.break_chunk) { hp.break_super = (int)k; break; }
 
   // position of the diagonal block of every row
   hp.diag.resize((size_t)N);
@@ -122,8 +137,8 @@ int build_host_pattern(int N, int E, int npe, const int *conn, HostPattern &hp,
   if (npe == 4) {
     std::vector<int> stamp((size_t)N, -1);
     int serial = 0;
-    for (int s0 = 0; s0 < nchunks; s0 += FEA_SUPER_CHUNKS) {
-      const int s1 = std::min(nchunks, s0 + FEA_SUPER_CHUNKS);
+    for (const auto &sp : supers) {
+      const int s0 = sp.first, s1 = sp.second;
       hp.super_achunk.push_back((int)hp.achunk.size());
       const int ra = hp.chunk[s0], rb = hp.chunk[s1];
       int r0 = ra;
@@ -162,8 +177,8 @@ int build_host_pattern(int N, int E, int npe, const int *conn, HostPattern &hp,
     std::vector<int> stamp((size_t)E, -1), nstamp((size_t)N, -1);
     int serial = 0;
     bool ok = true;
-    for (int s0 = 0; s0 < nchunks && ok; s0 += FEA_SUPER_CHUNKS) {
-      const int s1 = std::min(nchunks, s0 + FEA_SUPER_CHUNKS);
+    for (size_t sk = 0; sk < supers.size() && ok; ++sk) {
+      const int s0 = supers[sk].first, s1 = supers[sk].second;
       hp.super_achunk.push_back((int)hp.achunk.size());
       const int ra = hp.chunk[s0], rb = hp.chunk[s1];
       int r0 = ra;

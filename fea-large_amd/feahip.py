@@ -76,6 +76,13 @@ ABI = {
     "feahip_host_assembly_digest": [C.c_int, C.c_int, C.c_int, _ip, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), _ip],
     "feahip_assembly_in_use": [C.c_void_p, _ip],
     "feahip_node_numbering": [C.c_void_p, _ip],
+    "feahip_create_rank": [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _ip, _dp,
+                           C.c_int, _dp, C.c_int, C.c_int, _ip, _ip, _dp],
+    "feahip_rank_counts": [C.c_void_p, C.POINTER(C.c_longlong)],
+    "feahip_rank_maps": [C.c_void_p, _ip, _ip],
+    "feahip_host_rank_plan": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _dp, _ip, _ip, _ip, _ip, _ip, _ip],
+    "feahip_host_rank_mesh": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _dp, C.POINTER(C.c_longlong), _ip, _ip,
+                              C.POINTER(C.c_longlong), _ip],
     "feahip_copy_bandwidth": [C.c_void_p, C.c_longlong, _dp],
     "feahip_device_layout": [C.c_void_p, C.POINTER(C.c_longlong)],
     "feahip_host_numbering": [C.c_int, C.c_int, C.c_int, _ip, _dp, _ip],
@@ -552,18 +559,99 @@ def shard_plan(deck, rank, nranks):
             "recv": [ridx[roff[k]:roff[k + 1]].copy() for k in range(npeer)]}
 
 
+class RankSolver(FeaSolver):
+    """One rank's context of a sharded run (feahip_create_rank): the sub-mesh this rank holds, locally indexed (owned
+    nodes first).  node_global / elem_global say which nodes and elements of the deck the local ones are; every
+    node- or element-indexed method speaks local indices."""
+
+    def __init__(self, deck, rank, nranks, device=0):            # noqa: super().__init__ not called: another constructor of the ABI
+        self._lib = load_library()
+        self._ctx = C.c_void_p()
+        self.deck = deck
+        w, _, dforms = element_tables(deck.ele_type, deck.gauss_nodes_count)
+        self.npe, self.G = deck.nodes_per_element, deck.gauss_nodes_count
+        par = np.zeros(10)
+        par[:2] = deck.parameters[:2]
+        rc = self._lib.feahip_create_rank(
+            C.byref(self._ctx), device, rank, nranks, len(deck.nodes), len(deck.elements), self.npe, self.G, _d(w), _d(dforms),
+            _i(deck.elements), _d(deck.nodes), deck.model, _d(par), 2, len(deck.presc_node), _i(deck.presc_node),
+            _i(deck.presc_type), _d(deck.presc_values))
+        if rc != 0:
+            self._ctx = C.c_void_p()
+            raise FeaHipError(f"feahip_create_rank failed ({rc}): {self._lib.feahip_create_error().decode()}")
+        o = (C.c_longlong * 8)()
+        self._chk(self._lib.feahip_rank_counts(self._ctx, o))
+        self.N, self.n_own, self.E, self.N_global = int(o[0]), int(o[1]), int(o[2]), int(o[3])
+        self.nnzb_local, self.nnzb_owned, self.rows_sent, self.rows_received = int(o[4]), int(o[5]), int(o[6]), int(o[7])
+        self.ndof = 3 * self.N
+        self.node_global = np.empty(self.N, dtype=np.int32)
+        self.elem_global = np.empty(self.E, dtype=np.int32)
+        self._chk(self._lib.feahip_rank_maps(self._ctx, _i(self.node_global), _i(self.elem_global)))
+
+
+def host_rank_mesh(deck, rank, nranks, pattern=False):
+    """Host only: what rank `rank` of `nranks` would hold.  dict of counts; with pattern=True also node_global, elem_global
+    and the block rows of the owned nodes (rowptr, colidx in the deck's node ids)."""
+    lib = load_library()
+    el = np.ascontiguousarray(deck.elements, dtype=np.int32)
+    x = np.ascontiguousarray(deck.nodes, dtype=np.float64)
+    cnt = (C.c_longlong * 8)()
+    args = (rank, nranks, len(x), el.shape[0], el.shape[1], _i(el), _d(x))
+    rc = lib.feahip_host_rank_mesh(*args, cnt, None, None, None, None)
+    if rc != 0:
+        raise FeaHipError(f"feahip_host_rank_mesh failed ({rc})")
+    names = ("local_nodes", "owned_nodes", "local_elements", "blocks_owned_rows", "blocks_local_rows", "peers", "rows_sent", "rows_received")
+    out = {k: int(v) for k, v in zip(names, cnt)}
+    if pattern:
+        ng = np.empty(out["local_nodes"], dtype=np.int32); eg = np.empty(out["local_elements"], dtype=np.int32)
+        rp = np.empty(out["owned_nodes"] + 1, dtype=np.int64); ci = np.empty(max(out["blocks_owned_rows"], 1), dtype=np.int32)
+        rc = lib.feahip_host_rank_mesh(*args, cnt, _i(ng), _i(eg), rp.ctypes.data_as(C.POINTER(C.c_longlong)), _i(ci))
+        if rc != 0:
+            raise FeaHipError(f"feahip_host_rank_mesh failed ({rc})")
+        out.update(node_global=ng, elem_global=eg, rowptr=rp, colidx=ci[:out["blocks_owned_rows"]])
+    return out
+
+
+def host_rank_plan(deck, rank, nranks):
+    """Host only: halo plan of one rank's sub-mesh in the deck's node ids: dict(peers, send, recv)."""
+    lib = load_library()
+    el = np.ascontiguousarray(deck.elements, dtype=np.int32)
+    x = np.ascontiguousarray(deck.nodes, dtype=np.float64)
+    cnt = np.zeros(3, dtype=np.int32)
+    args = (rank, nranks, len(x), el.shape[0], el.shape[1], _i(el), _d(x))
+    if lib.feahip_host_rank_plan(*args, _i(cnt), None, None, None, None, None) != 0:
+        raise FeaHipError("feahip_host_rank_plan failed")
+    npeer, nsend, nrecv = (int(v) for v in cnt)
+    peers = np.zeros(max(npeer, 1), dtype=np.int32)
+    soff, roff = np.zeros(npeer + 1, dtype=np.int32), np.zeros(npeer + 1, dtype=np.int32)
+    sidx, ridx = np.zeros(max(nsend, 1), dtype=np.int32), np.zeros(max(nrecv, 1), dtype=np.int32)
+    if lib.feahip_host_rank_plan(*args, _i(cnt), _i(peers), _i(soff), _i(roff), _i(sidx), _i(ridx)) != 0:
+        raise FeaHipError("feahip_host_rank_plan failed")
+    return {"peers": [int(p) for p in peers[:npeer]],
+            "send": [sidx[soff[k]:soff[k + 1]].copy() for k in range(npeer)],
+            "recv": [ridx[roff[k]:roff[k + 1]].copy() for k in range(npeer)]}
+
+
 class FeaGroup:
     """n contexts of one mesh sharded by rows and driven from this process
     (feahip_group_* entries)."""
 
-    def __init__(self, deck, n, device=0):
+    def __init__(self, deck, n, device=0, rank_contexts=False):
+        """rank_contexts: every rank holds only its sub-mesh (RankSolver) instead of the whole mesh with a row shard."""
         self.deck, self.n = deck, n
-        self.ranks = [FeaSolver(deck, device=device) for _ in range(n)]
+        self.rank_contexts = rank_contexts
+        if rank_contexts:
+            self.ranks = [RankSolver(deck, r, n, device=device) for r in range(n)]
+        else:
+            self.ranks = [FeaSolver(deck, device=device) for _ in range(n)]
         self._lib = load_library()
         self._arr = (C.c_void_p * n)(*[r._ctx for r in self.ranks])
         self._chk(self._lib.feahip_group_init(self._arr, n))
-        self.rows = [r.owned_rows() for r in self.ranks]        # library ids
-        self.nodes = [r.owned_nodes() for r in self.ranks]      # the caller's ids of every rank's nodes
+        self.rows = [r.owned_rows() for r in self.ranks]        # library ids (local ids for rank contexts)
+        if rank_contexts:
+            self.nodes = [r.node_global[:r.n_own].astype(np.int64) for r in self.ranks]
+        else:
+            self.nodes = [r.owned_nodes() for r in self.ranks]  # the caller's ids of every rank's nodes
 
     def _chk(self, rc):
         if rc != 0:
@@ -601,6 +689,16 @@ class FeaGroup:
     def gather(self, name):
         """Owned rows of a per-node ([N][3]) or per-dof ([3N]) getter, stitched together."""
         parts = self.each(name)
+        if self.rank_contexts:                                  # local arrays: owned rows are the first n_own
+            first = parts[0]
+            out = np.zeros((len(self.deck.nodes), 3)) if first.ndim == 2 else np.zeros(3 * len(self.deck.nodes))
+            for r, p in zip(self.ranks, parts):
+                nd = r.node_global[:r.n_own].astype(np.int64)
+                if out.ndim == 2:
+                    out[nd] = p[:r.n_own]
+                else:
+                    out.reshape(-1, 3)[nd] = p.reshape(-1, 3)[:r.n_own]
+            return out
         out = parts[0].copy()
         for nd, p in zip(self.nodes, parts):
             if out.ndim == 2:

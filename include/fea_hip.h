@@ -180,6 +180,46 @@ int feahip_comm_init(feahip_ctx *ctx, int rank, int nranks, const void *unique_i
  * the caller's ids)                                                          */
 int feahip_owned_rows(feahip_ctx *ctx, int *row0, int *row1);
 
+/* A rank that holds only its slab.  feahip_create_rank takes the same arguments
+ * as feahip_create plus (rank, nranks) and builds the context of ONE rank: the
+ * nodes it owns (a slab of library ids), the elements that touch them, their
+ * halo nodes -- locally indexed, owned nodes first -- with the block rows, K,
+ * maps, vectors and multigrid hierarchy of that sub-mesh only, and the halo plan
+ * installed.  Nothing in it is sized by the whole mesh (the reference's single
+ * row-wise store, fea_solver.c:444-448, becomes nranks independent ones).  Its
+ * node- and element-indexed entries speak LOCAL indices: feahip_rank_maps says
+ * which nodes / elements of the caller's mesh they are; feahip_rank_counts:
+ * out8 = {local nodes, owned nodes (local ids [0, owned)), local elements,
+ * nodes of the whole mesh, blocks of all local rows, blocks of the owned rows,
+ * rows sent per exchange, rows received}.  After feahip_comm_init (same rank,
+ * nranks) or feahip_group_init the collective entries work as for row shards. */
+int feahip_create_rank(feahip_ctx **out, int device, int rank, int nranks,
+                       int n_nodes, int n_elems, int npe, int gauss_count,
+                       const double *gauss_weights, const double *dforms,
+                       const int *elements, const double *nodes0,
+                       int model, const double *model_params, int params_count,
+                       int n_presc, const int *presc_node, const int *presc_type,
+                       const double *presc_values);
+int feahip_rank_counts(feahip_ctx *ctx, long long *out8);
+int feahip_rank_maps(feahip_ctx *ctx, int *node_global, int *elem_global);
+/* Host-only (no device): the same sub-mesh without a context -- counts8 =
+ * {local nodes, owned nodes, local elements, blocks of the owned rows, blocks
+ * of all local rows, peers, rows sent, rows received}; with non-null arrays
+ * (sized by a first call): the caller's ids of the local nodes and elements,
+ * and the block rows of the OWNED nodes as the rank builds them from its own
+ * elements (rowptr[owned + 1], colidx = the caller's id of the column node).  */
+int feahip_host_rank_mesh(int rank, int nranks, int n_nodes, int n_elems, int npe,
+                          const int *elements, const double *nodes0, long long *counts8,
+                          int *node_global, int *elem_global, long long *rowptr, int *colidx);
+
+/* Host-only: that sub-mesh's halo plan in the caller's node ids -- counts3 =
+ * {peers, rows sent, rows received} by a first call with null lists, then
+ * peers[npeers], send_off / recv_off[npeers + 1], send_idx / recv_idx in the
+ * order the rows travel.                                                      */
+int feahip_host_rank_plan(int rank, int nranks, int n_nodes, int n_elems, int npe,
+                          const int *elements, const double *nodes0, int *counts3, int *peers,
+                          int *send_off, int *recv_off, int *send_idx, int *recv_idx);
+
 /* In-process group: n contexts of the same mesh (on any devices) driven by one
  * host thread; halo rows move by device copies, sums on the host.  Same
  * kernels and halo plan as the RCCL path.                                    */
