@@ -44,24 +44,6 @@ int ensure_generic_maps(feahip_ctx *c)
   return FEAHIP_OK;
 }
 
-int ensure_patches(feahip_ctx *c)
-{
-  if (c->have_patches || !c->h_pat || c->h_conn.empty()) return FEAHIP_OK;
-  HostPatches pt;
-  build_host_patches(c->N, c->E, c->h_conn.data(), *c->h_pat, pt);
-  if (!pt.ok) return FEAHIP_OK;
-  int rc;
-  if ((rc = dev_upload(c, &c->d_pdesc, pt.desc.data(), pt.desc.size()))) return rc;
-  if ((rc = dev_upload(c, &c->d_pnode, pt.pnode.data(), pt.pnode.size()))) return rc;
-  if ((rc = dev_upload(c, &c->d_pelem, pt.pelem.data(), pt.pelem.size()))) return rc;
-  if ((rc = dev_upload(c, &c->d_pent, pt.pent.data(), pt.pent.size()))) return rc;
-  if ((rc = dev_upload(c, &c->d_pbptr, pt.pbptr.data(), pt.pbptr.size()))) return rc;
-  c->have_patches = true;
-  c->patch_bytes = (long long)(pt.desc.size() * sizeof(PatchDesc) + pt.pnode.size() * 4 +
-                               pt.pelem.size() * 2 + pt.pent.size() * 2 + pt.pbptr.size() * 2);
-  return FEAHIP_OK;
-}
-
 // K for the rows of the shard installed now (see feahip_internal.h)
 int ensure_k(feahip_ctx *c)
 {
@@ -123,24 +105,6 @@ int ensure_visits(feahip_ctx *c)
   c->have_visits = true;
   c->nvisit_records = (int)(hv.vrec.size() / 2);
   c->visit_bytes = (long long)(hv.desc.size() * sizeof(VisitDesc) + hv.vnode.size() * 4 + hv.vrec.size() * 4);
-  return FEAHIP_OK;
-}
-
-int ensure_pairs(feahip_ctx *c)
-{
-  { const int rc = ensure_visits(c); if (rc) return rc; }
-  if (c->have_pairs || !c->have_visits || !c->h_pat || c->h_conn.empty()) return FEAHIP_OK;
-  HostVisits hv;                                    // the pairing starts from the visit maps: built again, host only
-  build_host_visits(c->N, c->E, c->h_conn.data(), *c->h_pat, hv);
-  if (!hv.ok) return FEAHIP_OK;
-  HostPairs pr;
-  build_host_pairs(c->h_conn.data(), *c->h_pat, hv, pr);
-  if (!pr.ok) return FEAHIP_OK;
-  int rc;
-  if ((rc = dev_upload(c, &c->d_pairdesc, pr.desc.data(), pr.desc.size()))) return rc;
-  if ((rc = dev_upload(c, &c->d_prec, pr.prec.data(), pr.prec.size()))) return rc;
-  c->have_pairs = true;
-  c->pair_bytes = (long long)(pr.desc.size() * sizeof(VisitDesc) + hv.vnode.size() * 4 + pr.prec.size() * 4);
   return FEAHIP_OK;
 }
 
@@ -259,7 +223,7 @@ static int create_impl(feahip_ctx *c, int device, int n_nodes, int n_elems, int 
 
   const bool lin1 = c->linear_tet && gauss_count == 1;
   if (lin1) {
-    // the maps of every linear-tet strategy (gather, staged visits, patches, pairs, generic incidence lists) are
+    // the maps of every linear-tet strategy (gather, staged visits, generic incidence lists) are
     // built the first time a launch asks for them, from these host copies -- for the rows this rank owns where
     // the strategy allows (gather)
     c->h_conn.assign(elements, elements + (size_t)n_elems * npe);
@@ -428,7 +392,7 @@ extern "C" void feahip_destroy(feahip_ctx *c)
   delete c->gather_lay; c->gather_lay = nullptr;
   delete c->gather10_lay; c->gather10_lay = nullptr;
   void *ptrs[] = {(void *)c->d_gmaps, (void *)c->d_g10_elist, (void *)c->d_g10_state, c->d_table, c->d_conn, c->d_X0, c->d_x, c->d_rowptr, c->d_colidx, c->d_K_alloc, c->d_Kstash_alloc,
-                  c->d_incptr, c->d_inc, c->d_incslot, c->d_chunk, c->d_diag, c->d_pdesc, c->d_pnode, c->d_pelem, c->d_pent, c->d_pbptr, c->d_vdesc, c->d_vnode, c->d_vrec, c->d_pairdesc, c->d_prec, c->d_qdesc, c->d_qelem, c->d_qpair, c->d_qnode, c->d_f, c->d_u, c->d_r, c->d_p,
+                  c->d_incptr, c->d_inc, c->d_incslot, c->d_chunk, c->d_diag, c->d_vdesc, c->d_vnode, c->d_vrec, c->d_qdesc, c->d_qelem, c->d_qpair, c->d_qnode, c->d_f, c->d_u, c->d_r, c->d_p,
                   c->d_q, c->d_minv, c->d_part, c->d_scal, c->d_flag, c->d_cdof, c->d_cval,
                   c->d_dofmask, c->d_F, c->d_S};
   for (void *p : ptrs)

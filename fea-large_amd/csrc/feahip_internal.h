@@ -25,7 +25,6 @@ struct ElemTable {            // element plug-in, tabulated by the host
   double dN[FEA_MAX_GAUSS][3][FEA_MAX_NPE];
 };
 
-struct PatchDesc;
 struct feahip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -79,12 +78,6 @@ struct feahip_ctx {
   uint8_t *d_incslot = nullptr;// [npe*E][npe] slot of column conn[e][b] in row
   int *d_chunk = nullptr;      // [nchunks+1] first row of every chunk
   int *d_diag = nullptr;       // [N] index of the diagonal block of every row
-  // PATCH assembly maps (linear tetrahedra)
-  bool have_patches = false;
-  PatchDesc *d_pdesc = nullptr;
-  int *d_pnode = nullptr;
-  uint16_t *d_pelem = nullptr, *d_pent = nullptr, *d_pbptr = nullptr;
-  long long patch_bytes = 0;
   // LDS-staged visit assembly maps (linear tetrahedra)
   bool have_visits = false, visits_failed = false;
   struct VisitDesc *d_vdesc = nullptr;
@@ -112,10 +105,6 @@ struct feahip_ctx {
   int *d_g10_elist = nullptr;            // this rank's elements
   double *d_g10_state = nullptr;         // [elements of the rank][G][18]: Gauss-point state records (kernels_gather10.hip)
   int g10_nloc = 0;
-  bool have_pairs = false;
-  struct VisitDesc *d_pairdesc = nullptr;
-  uint32_t *d_prec = nullptr;
-  long long pair_bytes = 0;
   // vectors (3N doubles)
   double *d_f = nullptr, *d_u = nullptr;
   double *d_r = nullptr, *d_p = nullptr, *d_q = nullptr, *d_minv = nullptr;
@@ -143,9 +132,8 @@ struct feahip_ctx {
 
   // host copies needed by getters / pattern export
   std::vector<int> h_rowptr, h_colidx;
-  // Linear tets assemble with the staged visit maps; the maps of the other strategies (generic incidence lists,
-  // patches, pairs: ~1.3 GB and ~2 s of host work at 10M tets) are built the first time a strategy asks for them,
-  // from these host copies.
+  // The maps of a strategy (gather chunks, staged visits, generic incidence lists) are built the first time it is
+  // asked for, from these host copies.
   std::vector<int> h_conn;
   struct HostPattern *h_pat = nullptr;
   bool generic_maps = false;   // incptr / inc / incslot uploaded
@@ -201,28 +189,7 @@ struct HostPattern {
 int build_host_pattern(int N, int E, int npe, const int *conn, HostPattern &hp,
                        std::string &err, int row_break = -1);
 
-// patches.cpp -- per-chunk maps of the PATCH assembly (kernels_patch.hip)
-#define FEA_PATCH_MAX_NODES 128      // unique nodes touched by one patch (LDS coordinate tile)
-#define FEA_PATCH_MAX_ENTRIES 1536   // off-diagonal block contributions of one patch
-#define FEA_PATCH_MAX_ELEMS 2048     // 11-bit element index inside an entry
-struct PatchDesc {                   // 48 bytes, one per chunk
-  int r0, r1;                        // rows [r0, r1)
-  int b0, nb;                        // blocks [b0, b0+nb) of the CSR
-  int node_off, nnode;               // into pnode
-  int elem_off, nelem;               // into pelem
-  int ent_off, nent;                 // into pent
-  int bptr_off, pad;                 // into pbptr (nb+1 entries)
-};
-struct HostPatches {
-  std::vector<PatchDesc> desc;
-  std::vector<int> pnode;            // global node id of every patch-local node
-  std::vector<uint16_t> pelem;       // [..][4] patch-local node ids of every patch element
-  std::vector<uint16_t> pent;        // elem(11) | la(2)<<11 | lb(2)<<13 | first(1)<<15
-  std::vector<uint16_t> pbptr;       // per patch nb+1 offsets into its entries
-  bool ok = false;                   // every chunk fits the limits above
-};
-void build_host_patches(int N, int E, const int *conn, const HostPattern &hp, HostPatches &out);
-
+// visits.cpp
 // LDS-staged visit assembly (kernels_visit.hip): per chunk, the nodes its
 // elements touch (owned rows first) and one 8-byte record per (row, element)
 // visit: 4 chunk-local node ids (row node first) + 3 column slots.
@@ -364,25 +331,14 @@ void build_host_gather10(int N, int E, int npe, const int *conn, const HostPatte
 int ensure_gather10(feahip_ctx *c);
 int launch_assemble_gather10(feahip_ctx *c, bool doK, bool doF);
 
-struct HostPairs {
-  std::vector<VisitDesc> desc;       // visit_off / nvisit = first pair / pairs of the chunk
-  std::vector<uint32_t> prec;        // [4 * pairs]: ids a,p,q,r | s,flags | slots p,q,r,s | 0
-  long long npairs_total = 0;
-  bool ok = false;
-};
-void build_host_pairs(const int *conn, const HostPattern &hp, const HostVisits &hv, HostPairs &out);
-int launch_assemble_pair(feahip_ctx *c, bool doK, bool doF);
-int launch_assemble_visit(feahip_ctx *c, bool doK, bool doF, bool pipelined);
+int launch_assemble_visit(feahip_ctx *c, bool doK, bool doF);
 
 // launchers (kernels_assemble.hip / kernels_patch.hip / kernels_solve.hip)
-int launch_assemble_patch(feahip_ctx *c, bool doF);
 int launch_assemble(feahip_ctx *c, bool doK, bool doF);
 int launch_state_export(feahip_ctx *c, double *d_grads = nullptr, double *d_detj = nullptr);
 int launch_apply_bc(feahip_ctx *c, double lambda);
 int launch_update_nodes_bc(feahip_ctx *c, double lambda);
 int ensure_generic_maps(feahip_ctx *c);
-int ensure_patches(feahip_ctx *c);
-int ensure_pairs(feahip_ctx *c);
 int ensure_k(feahip_ctx *c);
 void release_k(feahip_ctx *c);
 int ensure_visits(feahip_ctx *c);

@@ -305,8 +305,8 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
   AsmArgs A = make_args(c);
   const bool rowowner_ok = c->incslot_ok && c->max_rowlen <= FEA_CHUNK_BLOCKS;
   int strat = c->strategy;
-  // AUTO: row-owner visits, with LDS-staged coordinates where the maps exist (linear tets);
-  // PATCH is the bitwise-reproducible variant, slower today
+  // AUTO: the gather kernels where their maps build and their chunks are compact, the staged visits / the
+  // shared-state kernel behind them, the generic row-owner visits or the atomic scatter behind those
   if (strat == FEAHIP_ASM_AUTO) {
     if (c->linear_tet && c->G == 1 && c->h_pat) {
       // GATHER where the chunks of consecutive rows are compact enough that an element is evaluated at most ~2.5
@@ -340,7 +340,6 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
   }
   if (strat == FEAHIP_ASM_SHARED) { const int rc = ensure_quad(c); if (rc) return rc; }
   if (strat == FEAHIP_ASM_SHARED && !doK && c->have_quad) strat = rowowner_ok ? FEAHIP_ASM_ROWOWNER : FEAHIP_ASM_ATOMIC;   // residual alone: visit kernel
-  if (strat == FEAHIP_ASM_PATCH && !doK) strat = FEAHIP_ASM_ROWOWNER;                                                       // residual alone: visit kernel
   c->last_strategy = strat;                          // the kernel that runs, after the residual-only fallbacks
   if (strat == FEAHIP_ASM_SHARED) {
     if (!c->have_quad) {
@@ -368,32 +367,18 @@ int launch_assemble(feahip_ctx *c, bool doK, bool doF)
     if (doK) FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));
     return launch_assemble_gather(c, doK, doF);
   }
-  if (strat == FEAHIP_ASM_PAIRED) {
-    { const int rc = ensure_pairs(c); if (rc) return rc; }
-    if (!c->have_pairs) {
-      c->err = "paired assembly needs linear tetrahedra whose chunks fit the LDS tiles";
-      return FEAHIP_EINVAL;
-    }
-    if (doK) FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));
-    return launch_assemble_pair(c, doK, doF);
+  if (strat == FEAHIP_ASM_PAIRED || strat == FEAHIP_ASM_PATCH || strat == FEAHIP_ASM_PIPELINED) {
+    c->err = "this assembly strategy was retired (measured slower than the staged visits and the gather kernel: DESIGN.md)";
+    return FEAHIP_EINVAL;
   }
-  if (strat == FEAHIP_ASM_STAGED || strat == FEAHIP_ASM_PIPELINED) {
+  if (strat == FEAHIP_ASM_STAGED) {
     { const int rc = ensure_visits(c); if (rc) return rc; }
     if (!c->have_visits) {
       c->err = "staged assembly needs linear tetrahedra whose chunks fit the LDS tiles";
       return FEAHIP_EINVAL;
     }
     if (doK) FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));
-    return launch_assemble_visit(c, doK, doF, strat == FEAHIP_ASM_PIPELINED);
-  }
-  if (strat == FEAHIP_ASM_PATCH) {
-    { const int rc = ensure_patches(c); if (rc) return rc; }
-    if (!c->have_patches) {
-      c->err = "patch assembly needs linear tetrahedra whose chunks fit the LDS tiles";
-      return FEAHIP_EINVAL;
-    }
-    FEA_HIP_CHECK(c, hipMemsetAsync(c->d_flag + 1, 0, sizeof(int), c->stream));
-    return launch_assemble_patch(c, doF);
+    return launch_assemble_visit(c, doK, doF);
   }
   { const int rc = ensure_generic_maps(c); if (rc) return rc; }     // the generic kernels walk the incidence lists
   A.incptr = c->d_incptr; A.inc = c->d_inc; A.incslot = c->d_incslot;

@@ -1,17 +1,6 @@
-// patches.cpp -- one-time host construction of the maps the PATCH assembly
-// kernel (kernels_patch.hip) walks.
-//
-// A patch is one chunk of consecutive block rows.  For every patch:
-//   pnode   the unique nodes its elements touch (their coordinates are
-//           staged in LDS once per launch),
-//   pelem   the unique elements that touch its rows, as 4 patch-local node
-//           ids each (every element state is evaluated once per patch, not
-//           once per (element, node) visit),
-//   pent    for every off-diagonal block of the patch, the list of
-//           (element, local row node, local column node) contributions that
-//           sum to it, in ascending patch-element order (fixed summation
-//           order => bitwise reproducible assembly).
-// Diagonal blocks have no entries: they are minus the sum of their row.
+// visits.cpp -- one-time host construction of the maps of the staged-visit assembly of linear tetrahedra
+// (kernels_visit.hip): per assembly chunk the nodes its elements touch and one 8-byte record per (row, element) visit,
+// scheduled against the LDS banks.
 #include "feahip_internal.h"
 #include <algorithm>
 #include <cstdlib>
@@ -32,106 +21,7 @@ void par_for(int n, F f)
   }
   for (auto &x : th) x.join();
 }
-
-struct Local {            // one patch, built independently
-  std::vector<int> nodes;
-  std::vector<uint16_t> elems, ents, bptr;
-  bool ok = true;
-};
 }  // namespace
-
-void build_host_patches(int N, int E, const int *conn, const HostPattern &hp, HostPatches &out)
-{
-  (void)N; (void)E;
-  const int np = (int)hp.chunk.size() - 1;
-  std::vector<Local> loc((size_t)np);
-  par_for(np, [&](int lo, int hi) {
-    std::vector<int> el, order;
-    std::vector<std::pair<int, uint16_t>> tmp;      // (block, entry)
-    for (int p = lo; p < hi; ++p) {
-      Local &L = loc[p];
-      const int r0 = hp.chunk[p], r1 = hp.chunk[p + 1];
-      const int b0 = hp.rowptr[r0], nb = hp.rowptr[r1] - b0;
-      // unique elements of the patch
-      el.clear();
-      for (int q = hp.incptr[r0]; q < hp.incptr[r1]; ++q) el.push_back((int)(hp.inc[q] & 0x0FFFFFFFu));
-      std::sort(el.begin(), el.end());
-      el.erase(std::unique(el.begin(), el.end()), el.end());
-      const int ne = (int)el.size();
-      // spread every batch of 64 elements over the whole patch: stride walk
-      // with a stride coprime to ne (keeps the per-batch work of the block
-      // owners even)
-      order.assign(el.begin(), el.end());
-      if (ne > 64) {
-        int stride = (int)(ne * 0.6180339887) | 1;
-        auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
-        while (gcd(stride, ne) != 1) stride += 2;
-        for (int i = 0; i < ne; ++i) order[i] = el[(int)(((long long)i * stride) % ne)];
-      }
-      // unique nodes
-      L.nodes.clear();
-      for (int e : order) for (int k = 0; k < 4; ++k) L.nodes.push_back(conn[(size_t)e * 4 + k]);
-      std::sort(L.nodes.begin(), L.nodes.end());
-      L.nodes.erase(std::unique(L.nodes.begin(), L.nodes.end()), L.nodes.end());
-      auto lnode = [&](int g) { return (int)(std::lower_bound(L.nodes.begin(), L.nodes.end(), g) - L.nodes.begin()); };
-      L.elems.resize((size_t)ne * 4);
-      for (int i = 0; i < ne; ++i)
-        for (int k = 0; k < 4; ++k) L.elems[(size_t)i * 4 + k] = (uint16_t)lnode(conn[(size_t)order[i] * 4 + k]);
-      // contributions, bucketed by block
-      tmp.clear();
-      for (int i = 0; i < ne; ++i) {
-        const int *c = conn + (size_t)order[i] * 4;
-        for (int la = 0; la < 4; ++la) {
-          const int a = c[la];
-          if (a < r0 || a >= r1) continue;         // row owned by another patch
-          const int *cb = hp.colidx.data() + hp.rowptr[a], *ce = hp.colidx.data() + hp.rowptr[a + 1];
-          bool first = true;
-          for (int lb = 0; lb < 4; ++lb) {
-            if (lb == la) continue;
-            const int blk = hp.rowptr[a] - b0 + (int)(std::lower_bound(cb, ce, c[lb]) - cb);
-            tmp.emplace_back(blk, (uint16_t)(i | (la << 11) | (lb << 13) | ((first ? 1 : 0) << 15)));
-            first = false;
-          }
-        }
-      }
-      std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<int, uint16_t> &x, const std::pair<int, uint16_t> &y) { return x.first < y.first; });
-      L.ents.resize(tmp.size());
-      L.bptr.assign((size_t)nb + 1, 0);
-      for (size_t i = 0; i < tmp.size(); ++i) { L.ents[i] = tmp[i].second; L.bptr[tmp[i].first + 1]++; }
-      for (int b = 0; b < nb; ++b) L.bptr[b + 1] = (uint16_t)(L.bptr[b + 1] + L.bptr[b]);
-      L.ok = ne <= FEA_PATCH_MAX_ELEMS && (int)L.nodes.size() <= FEA_PATCH_MAX_NODES &&
-             (int)tmp.size() <= FEA_PATCH_MAX_ENTRIES && nb <= FEA_CHUNK_BLOCKS;
-    }
-  });
-  out.ok = true;
-  out.desc.resize((size_t)np);
-  size_t no = 0, eo = 0, to = 0, bo = 0;
-  for (int p = 0; p < np; ++p) {
-    const Local &L = loc[p];
-    if (!L.ok) out.ok = false;
-    PatchDesc &d = out.desc[p];
-    d.r0 = hp.chunk[p]; d.r1 = hp.chunk[p + 1];
-    d.b0 = hp.rowptr[d.r0]; d.nb = hp.rowptr[d.r1] - d.b0;
-    d.node_off = (int)no; d.nnode = (int)L.nodes.size();
-    d.elem_off = (int)eo; d.nelem = (int)(L.elems.size() / 4);
-    d.ent_off = (int)to; d.nent = (int)L.ents.size();
-    d.bptr_off = (int)bo; d.pad = 0;
-    no += L.nodes.size(); eo += L.elems.size() / 4; to += L.ents.size(); bo += L.bptr.size();
-    if (no > 0x7FFFFFFFull || to > 0x7FFFFFFFull) { out.ok = false; break; }
-  }
-  if (!out.ok) { out.desc.clear(); return; }
-  out.pnode.resize(no); out.pelem.resize(eo * 4); out.pent.resize(to); out.pbptr.resize(bo);
-  par_for(np, [&](int lo, int hi) {
-    for (int p = lo; p < hi; ++p) {
-      const Local &L = loc[p];
-      const PatchDesc &d = out.desc[p];
-      std::copy(L.nodes.begin(), L.nodes.end(), out.pnode.begin() + d.node_off);
-      std::copy(L.elems.begin(), L.elems.end(), out.pelem.begin() + (size_t)d.elem_off * 4);
-      std::copy(L.ents.begin(), L.ents.end(), out.pent.begin() + d.ent_off);
-      std::copy(L.bptr.begin(), L.bptr.end(), out.pbptr.begin() + d.bptr_off);
-    }
-  });
-}
 
 // ---------------------------------------------------------------------------
 // visit records for kernels_visit.hip
@@ -443,160 +333,6 @@ void build_host_visits(int N, int E, const int *conn, const HostPattern &hp, Hos
   if (hp.max_rowlen > 255) { out.desc.clear(); out.vrec.clear(); out.vnode.clear(); return; }
   out.ok = true;
 }
-
-// ---------------------------------------------------------------------------
-// paired visits for kernels_visit.hip (k_assemble_pair)
-//
-// Two elements around a row node a that share a face through a -- (a,p,q,r)
-// and (a,p,q,s) -- both add to the blocks (a,p) and (a,q).  One lane takes
-// the pair: it sums those two blocks in registers and adds them to the LDS
-// tile once, and it reads only one new node for the second element.  Per
-// visit that is 18 instead of 27 LDS adds and 7.5 instead of 12 LDS reads.
-// The pairing is a greedy matching on the face-adjacency graph of the row's
-// elements (3-regular for interior nodes); leftovers run as single visits.
-// ---------------------------------------------------------------------------
-void build_host_pairs(const int *conn, const HostPattern &hp, const HostVisits &hv, HostPairs &out)
-{
-  out.ok = false;
-  if (!hv.ok) return;
-  const int np = (int)hv.desc.size();
-  out.desc = hv.desc;
-  std::vector<std::vector<uint32_t>> recs((size_t)np);
-  std::vector<char> bad((size_t)np, 0);
-  par_for(np, [&](int lo, int hi) {
-    for (int p = lo; p < hi; ++p) {
-      const VisitDesc &d = hv.desc[p];
-      const int r0 = d.r0, r1 = d.r1, nown = r1 - r0;
-      const int *vn = hv.vnode.data() + (size_t)p * FEA_VISIT_MAX_NODES;
-      std::vector<std::pair<int, int>> byg;                          // (global id, chunk-local id) of the halo nodes
-      for (int k = nown; k < d.nnode; ++k) byg.push_back({vn[k], k});
-      std::sort(byg.begin(), byg.end());
-      auto lid = [&](int g) {
-        if (g >= r0 && g < r1) return g - r0;
-        return std::lower_bound(byg.begin(), byg.end(), std::make_pair(g, 0))->second;
-      };
-      struct P { int row; int eA, laA, eB, laB; int p, q, r, s; };   // global node ids; eB < 0: single
-      std::vector<P> pairs;
-      for (int r = r0; r < r1; ++r) {
-        const int q0 = hp.incptr[r], nv = hp.incptr[r + 1] - q0;
-        std::vector<int> mate((size_t)nv, -1);
-        std::vector<std::vector<int>> adj((size_t)nv);
-        auto others = [&](int v, int (&o)[3]) {
-          const int e = (int)(hp.inc_rows[q0 + v] & 0x0FFFFFFFu), la = (int)(hp.inc_rows[q0 + v] >> 28);
-          int m = 0;
-          for (int k = 0; k < 4; ++k) if (k != la) o[m++] = conn[(size_t)e * 4 + k];
-        };
-        for (int v = 0; v < nv; ++v)
-          for (int w = v + 1; w < nv; ++w) {
-            int a3[3], b3[3], common = 0;
-            others(v, a3); others(w, b3);
-            for (int x : a3) for (int y : b3) common += (x == y);
-            if (common == 2) { adj[v].push_back(w); adj[w].push_back(v); }
-          }
-        // greedy matching, fewest free neighbours first
-        for (;;) {
-          int best = -1, bestdeg = 1 << 30;
-          for (int v = 0; v < nv; ++v) {
-            if (mate[v] >= 0) continue;
-            int dg = 0;
-            for (int w : adj[v]) dg += mate[w] < 0;
-            if (dg > 0 && dg < bestdeg) { bestdeg = dg; best = v; }
-          }
-          if (best < 0) break;
-          int bw = -1, bwdeg = 1 << 30;
-          for (int w : adj[best]) {
-            if (mate[w] >= 0) continue;
-            int dg = 0;
-            for (int z : adj[w]) dg += mate[z] < 0;
-            if (dg < bwdeg) { bwdeg = dg; bw = w; }
-          }
-          mate[best] = bw; mate[bw] = best;
-        }
-        for (int v = 0; v < nv; ++v) {
-          if (mate[v] >= 0 && mate[v] < v) continue;
-          P pr; pr.row = r - r0;
-          pr.eA = (int)(hp.inc_rows[q0 + v] & 0x0FFFFFFFu); pr.laA = (int)(hp.inc_rows[q0 + v] >> 28);
-          int a3[3]; others(v, a3);
-          if (mate[v] < 0) { pr.eB = -1; pr.laB = 0; pr.p = a3[0]; pr.q = a3[1]; pr.r = a3[2]; pr.s = a3[2]; }
-          else {
-            const int w = mate[v];
-            pr.eB = (int)(hp.inc_rows[q0 + w] & 0x0FFFFFFFu); pr.laB = (int)(hp.inc_rows[q0 + w] >> 28);
-            int b3[3]; others(w, b3);
-            int sh[2], ns = 0; pr.r = -1; pr.s = -1;
-            for (int x : a3) { bool in = false; for (int y : b3) in |= (x == y); if (in) sh[ns++] = x; else pr.r = x; }
-            for (int y : b3) { bool in = false; for (int x : a3) in |= (x == y); if (!in) pr.s = y; }
-            pr.p = sh[0]; pr.q = sh[1];
-          }
-          pairs.push_back(pr);
-        }
-      }
-      if ((int)pairs.size() > FEA_VISIT_MAX_VISITS) { bad[p] = 1; continue; }
-      // passes of 64 lanes: rows round-robin; inside a pass greedy choice of (p<->q, A<->B) so that the four
-      // add steps (r, s, p, q) of a row's lanes hit different columns
-      std::vector<std::vector<P>> per((size_t)nown);
-      for (auto &pr : pairs) per[(size_t)pr.row].push_back(pr);
-      std::vector<P> order;
-      for (size_t k = 0;; ++k) {
-        bool any = false;
-        for (auto &v : per) if (k < v.size()) { order.push_back(v[k]); any = true; }
-        if (!any) break;
-      }
-      const int nrounds = ((int)order.size() + 63) / 64;
-      std::vector<uint8_t> used((size_t)nrounds * nown * 4 * 256, 0);
-      auto U = [&](int rd, int row, int step, int slot) -> uint8_t & { return used[(((size_t)rd * nown + row) * 4 + step) * 256 + slot]; };
-      std::vector<uint32_t> &out_rec = recs[p];
-      out_rec.resize(order.size() * 4);
-      for (int i = 0; i < (int)order.size(); ++i) {
-        P pr = order[i];
-        const int rd = i / 64, a = r0 + pr.row;
-        const int *cb = hp.colidx.data() + hp.rowptr[a], *ce = hp.colidx.data() + hp.rowptr[a + 1];
-        auto slot = [&](int g) { return (int)(std::lower_bound(cb, ce, g) - cb); };
-        int bestc = 1 << 30, bestcfg = 0;
-        for (int cfg = 0; cfg < (pr.eB >= 0 ? 4 : 2); ++cfg) {
-          const int pp = (cfg & 1) ? pr.q : pr.p, qq = (cfg & 1) ? pr.p : pr.q;
-          const int rr = (cfg & 2) ? pr.s : pr.r, ss = (cfg & 2) ? pr.r : pr.s;
-          int c = U(rd, pr.row, 0, slot(rr)) + U(rd, pr.row, 2, slot(pp)) + U(rd, pr.row, 3, slot(qq));
-          if (pr.eB >= 0) c += U(rd, pr.row, 1, slot(ss));
-          if (c < bestc) { bestc = c; bestcfg = cfg; }
-        }
-        if (bestcfg & 1) std::swap(pr.p, pr.q);
-        if (bestcfg & 2) { std::swap(pr.r, pr.s); std::swap(pr.eA, pr.eB); std::swap(pr.laA, pr.laB); }
-        U(rd, pr.row, 0, slot(pr.r))++; U(rd, pr.row, 2, slot(pr.p))++; U(rd, pr.row, 3, slot(pr.q))++;
-        if (pr.eB >= 0) U(rd, pr.row, 1, slot(pr.s))++;
-        // orientation parity of (a,p,q,r) w.r.t. the stored element A, and of (a,p,q,s) w.r.t. B
-        auto parity = [&](int e, int g0, int g1, int g2, int g3) {
-          int pos[4];
-          const int g[4] = {g0, g1, g2, g3};
-          for (int k = 0; k < 4; ++k) { pos[k] = 0; for (int m = 0; m < 4; ++m) if (conn[(size_t)e * 4 + m] == g[k]) pos[k] = m; }
-          int inv = 0;
-          for (int x = 0; x < 4; ++x) for (int y = x + 1; y < 4; ++y) inv += pos[x] > pos[y];
-          return inv & 1;
-        };
-        uint32_t flags = (uint32_t)parity(pr.eA, a, pr.p, pr.q, pr.r);
-        if (pr.eB >= 0) flags |= (uint32_t)parity(pr.eB, a, pr.p, pr.q, pr.s) << 1 | 4u;
-        out_rec[(size_t)i * 4 + 0] = (uint32_t)lid(a) | (uint32_t)lid(pr.p) << 8 | (uint32_t)lid(pr.q) << 16 | (uint32_t)lid(pr.r) << 24;
-        out_rec[(size_t)i * 4 + 1] = (uint32_t)lid(pr.s) | flags << 8;
-        out_rec[(size_t)i * 4 + 2] = (uint32_t)slot(pr.p) | (uint32_t)slot(pr.q) << 8 | (uint32_t)slot(pr.r) << 16 | (uint32_t)slot(pr.s) << 24;
-        out_rec[(size_t)i * 4 + 3] = 0;
-      }
-    }
-  });
-  size_t tot = 0;
-  for (int p = 0; p < np; ++p) {
-    if (bad[p]) return;
-    out.desc[p].visit_off = (int)tot;                    // pair offset
-    out.desc[p].nvisit = (int)(recs[p].size() / 4);      // pairs (incl. singles)
-    tot += recs[p].size() / 4;
-  }
-  out.prec.resize(tot * 4);
-  par_for(np, [&](int lo, int hi) {
-    for (int p = lo; p < hi; ++p)
-      std::copy(recs[p].begin(), recs[p].end(), out.prec.begin() + (size_t)out.desc[p].visit_off * 4);
-  });
-  out.npairs_total = (long long)tot;
-  out.ok = true;
-}
-
 // ---------------------------------------------------------------------------
 // maps of the shared-state assembly of 10-node elements (kernels_quad.hip)
 // ---------------------------------------------------------------------------

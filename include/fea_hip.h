@@ -46,20 +46,14 @@ enum {
   FEAHIP_ASM_ROWOWNER = 1, /* node-centric gather, every CSR value written
                               once, deterministic                            */
   FEAHIP_ASM_ATOMIC = 2,   /* element-parallel, FP64 atomics into the CSR    */
-  FEAHIP_ASM_PATCH = 3,    /* linear tets: element states shared through LDS,
-                              block owners gather; no atomics, bitwise
-                              reproducible                                   */
+  FEAHIP_ASM_PATCH = 3,    /* retired (refused): element states shared through
+                              LDS per 16-row chunk; 1.8x slower than STAGED   */
   FEAHIP_ASM_STAGED = 4,   /* linear tets: row-owner visits with node
                               coordinates and connectivity staged in LDS     */
-  FEAHIP_ASM_PAIRED = 5,   /* STAGED with two face-sharing elements per lane:
-                              shared blocks summed in registers (fewer LDS
-                              operations; measured 5 % slower than STAGED
-                              for K+f, 8 % faster for f alone)               */
-  FEAHIP_ASM_PIPELINED = 6,/* STAGED, one wave walking a run of chunks with
-                              the next chunk's loads (LDS-DMA) in flight
-                              under the current one; hides the load latency
-                              but the LDS adds bound both: equal to STAGED
-                              within 2 %                         */
+  FEAHIP_ASM_PAIRED = 5,   /* retired (refused): two face-sharing elements per
+                              lane; 5 % slower than STAGED                    */
+  FEAHIP_ASM_PIPELINED = 6,/* retired (refused): STAGED with the next chunk's
+                              loads in flight; equal to STAGED within 2 %     */
   FEAHIP_ASM_SHARED = 7,   /* 10-node tets: Gauss-point states evaluated once
                               per chunk element and shared through LDS, the
                               blocks of a (row, element, column) pair summed

@@ -1,4 +1,4 @@
-// host-only sanitizer run over the map builders (pattern, visits, pairs, patches, gather, quad, multigrid setup)
+// host-only sanitizer run over the map builders (pattern, visits, gather, quad, numbering, rank sub-mesh, multigrid setup)
 #include "feahip_internal.h"
 #include "amg.h"
 #include <cstdio>
@@ -25,13 +25,11 @@ int main()
     HostPattern hp; std::string err;
     if (build_host_pattern(N, E, npe, conn.data(), hp, err)) { printf("pattern: %s\n", err.c_str()); return 1; }
     if (!quad) {
-      HostPatches pt; build_host_patches(N, E, conn.data(), hp, pt);
       HostVisits hv; build_host_visits(N, E, conn.data(), hp, hv);
-      HostPairs pr; build_host_pairs(conn.data(), hp, hv, pr);
       HostGather hg; build_host_gather(N, E, conn.data(), hp, 0, N, hg);
       HostGather hs; build_host_gather(N, E, conn.data(), hp, N / 3, 2 * N / 3, hs);      // a rank's rows only
-      printf("tet4: N=%d E=%d chunks=%zu achunks=%zu patches=%d visits=%d pairs=%d gather=%d/%d gather chunks=%d evaluations per element=%.2f\n", N, E,
-             hp.chunk.size() - 1, hp.achunk.size() - 1, (int)pt.ok, (int)hv.ok, (int)pr.ok, (int)hg.ok, (int)hs.ok, hg.nchunks,
+      printf("tet4: N=%d E=%d chunks=%zu achunks=%zu visits=%d gather=%d/%d gather chunks=%d evaluations per element=%.2f\n", N, E,
+             hp.chunk.size() - 1, hp.achunk.size() - 1, (int)hv.ok, (int)hg.ok, (int)hs.ok, hg.nchunks,
              hg.distinct_elems ? (double)hg.total_evals / (double)hg.distinct_elems : 0.0);
     } else {
       const int na = (int)hp.achunk.size() - 1;
@@ -56,8 +54,17 @@ int main()
     printf("  amg: ok=%d levels=%zu", (int)ok, lv.size());
     for (auto &L : lv) printf(" [N=%d S=%d Sc=%d nnzb=%zu]", L.N, L.S, L.Sc, L.colidx.size());
     printf("\n");
-    ShardPlan sp;
-    (void)sp;
+    {                                       // the library's numbering and one rank's sub-mesh with its own pattern
+      std::vector<int> lib;
+      const bool ren = locality_numbering(N, E, npe, conn.data(), pos.data(), lib);
+      RankMesh rm;
+      const int rc = build_rank_mesh(1, 3, N, E, npe, conn.data(), pos.data(), 0, nullptr, nullptr, nullptr, rm, err);
+      HostPattern hl;
+      const int rc2 = rc ? rc : build_host_pattern((int)rm.node_global.size(), (int)rm.elem_global.size(), npe, rm.elements.data(), hl, err, rm.n_own);
+      printf("  numbering=%d rank mesh: rc=%d/%d owned %d of %zu local nodes, %zu elements, peers %zu\n", (int)ren, rc, rc2, rm.n_own,
+             rm.node_global.size(), rm.elem_global.size(), rm.plan.peer.size());
+      if (rc || rc2) return 3;
+    }
   }
   return 0;
 }

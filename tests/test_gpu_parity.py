@@ -38,7 +38,7 @@ def make_pair(deck, x=None):
 
 def check_assembly(s, o, strategies=(feahip.ASM_ROWOWNER, feahip.ASM_ATOMIC)):
     if s.npe == 4 and s.G == 1:
-        strategies = tuple(strategies) + (feahip.ASM_PATCH, feahip.ASM_STAGED, feahip.ASM_PAIRED, feahip.ASM_PIPELINED, feahip.ASM_GATHER)
+        strategies = tuple(strategies) + (feahip.ASM_STAGED, feahip.ASM_GATHER)
     if s.npe == 10:
         strategies = tuple(strategies) + (feahip.ASM_SHARED, feahip.ASM_GATHER)
     o.update_state()
@@ -99,20 +99,6 @@ def test_tet10_four_point_rule(decks_dir):
     deck.gauss_nodes_count = 4
     s, o = make_pair(deck, mesh.deformed_state(deck.nodes, k1=1.03))
     check_assembly(s, o, strategies=(feahip.ASM_ROWOWNER,))
-    s.close()
-
-
-def test_patch_assembly_is_bitwise_reproducible():
-    deck = mesh.bar_deck(dims=(5, 9, 4))
-    s = feahip.FeaSolver(deck)
-    s.set_nodes(mesh.deformed_state(deck.nodes))
-    s.set_assembly(feahip.ASM_PATCH)
-    s.create_stiffness_and_residual()
-    v1, f1 = s.matrix_yale()[2], s.forces()
-    s.create_stiffness_and_residual()
-    assert np.array_equal(v1, s.matrix_yale()[2]) and np.array_equal(f1, s.forces())
-    s.create_stiffness()                                  # K alone: same bits
-    assert np.array_equal(v1, s.matrix_yale()[2])
     s.close()
 
 

@@ -231,12 +231,12 @@ def test_host_map_builders_under_sanitizers(tmp_path):
     cmd = ["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17",
            "-I" + src, "-I" + os.path.join(root, "include"), "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-o", exe,
            os.path.join(root, "tests", "host_asan.cpp")] + [os.path.join(src, f) for f in
-                                                            ("pattern.cpp", "patches.cpp", "gather.cpp", "gather10.cpp", "shard.cpp", "amg_setup.cpp")] + ["-lpthread"]
+                                                            ("pattern.cpp", "visits.cpp", "gather.cpp", "gather10.cpp", "shard.cpp", "renumber.cpp", "rankmesh.cpp", "amg_setup.cpp")] + ["-lpthread"]
     subprocess.run(cmd, check=True, capture_output=True, timeout=600)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "ERROR" not in r.stderr and "runtime error" not in r.stderr
-    assert "patches=1 visits=1 pairs=1 gather=1/1" in r.stdout and "quad=1/1" in r.stdout and "gather10=1/1" in r.stdout and r.stdout.count("amg: ok=1") == 2
+    assert "visits=1 gather=1/1" in r.stdout and r.stdout.count("rank mesh: rc=0/0") == 2 and "quad=1/1" in r.stdout and "gather10=1/1" in r.stdout and r.stdout.count("amg: ok=1") == 2
 
 
 @pytest.mark.parametrize("quadratic,brick", [(False, None), (False, (4, 4, 4)), (True, None), (True, (3, 4, 4))])
