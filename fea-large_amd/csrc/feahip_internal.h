@@ -243,7 +243,7 @@ int launch_assemble_quad(feahip_ctx *c, bool doF);
 #ifndef FEA_G_BIG
 #define FEA_G_BIG 1
 #endif
-#if FEA_G_BIG
+#if FEA_G_BIG == 1
 #define FEA_G_THREADS 1024            // one workgroup per CU: sixteen waves share one chunk's records (see kernels_gather.hip)
 #define FEA_G_TASK_THREADS 768        // block and residual threads: waves 0-11; waves 12-15 (FEA_G_DIAG_LANES) sum the diagonal blocks
 #define FEA_G_MAX_ROWS 64
@@ -251,6 +251,14 @@ int launch_assemble_quad(feahip_ctx *c, bool doF);
 #define FEA_G_MAX_ELEMS 719           // slots come in sixteens and one stays all-zero; 45 x 16 = 720 records of 208 B fill the LDS next to the coordinates
 #define FEA_G_ELEMS_TARGET 672        // a 4 x 4 x 4 brick of nodes of a Kuhn block
 #define FEA_G_CELL 4, 4, 4
+#elif FEA_G_BIG == 2
+#define FEA_G_THREADS 512             // two workgroups per CU, eight waves each
+#define FEA_G_TASK_THREADS 384
+#define FEA_G_MAX_ROWS 32
+#define FEA_G_MAX_NODES 128
+#define FEA_G_MAX_ELEMS 351           // 22 x 16 = 352 records of 208 B + the coordinates: 80 KB
+#define FEA_G_ELEMS_TARGET 320        // a 4 x 3 x 2 brick of nodes of a Kuhn block touches 300 elements
+#define FEA_G_CELL 4, 2, 3
 #else
 #define FEA_G_THREADS 256             // three workgroups per CU
 #define FEA_G_TASK_THREADS 192
@@ -294,11 +302,17 @@ int launch_assemble_gather(feahip_ctx *c, bool doK, bool doF);
 // Gauss points as an outer loop: a 256-thread workgroup owns up to 64 consecutive block rows, evaluates every
 // distinct element touching them once per Gauss point into LDS records (spatial gradient g_k and traction vector
 // t_k of its ten nodes), and every thread sums up to five off-diagonal blocks over all Gauss points in registers.
-#define FEA_Q_THREADS 256
+#ifndef FEA_Q_THREADS
+#define FEA_Q_THREADS 256             // two workgroups per CU (the accumulators of five blocks per thread take the register file:
+                                      // 384 threads x 4 blocks and 512 x 3 spill 240-370 bytes per lane at their register budgets)
+#endif
+#define FEA_Q_WAVES (FEA_Q_THREADS / 64)
 #define FEA_Q_MAX_ROWS 64
 #define FEA_Q_MAX_NODES 240           // 8-bit chunk-local node ids
 #define FEA_Q_MAX_ELEMS 127           // 7-bit record slot; the slot after the last one in use is the all-zero record
+#ifndef FEA_Q_SLOTS
 #define FEA_Q_SLOTS 5                 // blocks per thread
+#endif
 #define FEA_Q_REGW 4                  // contribution words per block a thread keeps in registers (2 entries each)
 #define FEA_Q_MAX_PASS 7              // write-out passes of one chunk through the K tile
 #define FEA_Q_FLANES 128              // residual lanes (the last two waves)
@@ -308,10 +322,12 @@ struct Gather10Header {              // 128 bytes
   int nnode, nelem, ntask, npass;
   int nft, fdw;                      // residual lanes, words per residual lane (2 visits each)
   unsigned char prow[8];             // pass p writes the rows [prow[p], prow[p+1]) of the chunk
-  unsigned char cnt[FEA_Q_SLOTS * 4];// contributions of the longest list among the 64 blocks wave w holds in slot s, at [4 s + w]
-  unsigned char sw[8];               // list words stored for slot s (the longest of its four waves); rows of the clist section
-  int pad[13];
+  unsigned char cnt[40];             // contributions of the longest list among the 64 blocks wave w holds in slot s, at [FEA_Q_WAVES s + w]
+  unsigned char sw[8];               // list words stored for slot s (the longest of its waves); rows of the clist section
+  int pad[8];
 };
+static_assert(FEA_Q_SLOTS * FEA_Q_WAVES <= 40 && FEA_Q_SLOTS <= 8, "Gather10Header: cnt / sw too small");
+static_assert(sizeof(Gather10Header) == 128, "Gather10Header is 128 bytes");
 struct Gather10Layout {
   int stride;
   int o_nodes, o_elems, o_rows, o_tpos, o_flist, o_clist;

@@ -194,13 +194,13 @@ void build_host_gather10(int N, int E, int npe, const int *conn, const HostPatte
       memset(&h, 0, sizeof(h));
       bool too_long = false;
       for (int i = 0; i < ntask; ++i) {
-        const int run = i / 64, s = run / 4, wv = (s & 1) ? 3 - (run & 3) : (run & 3);
+        const int run = i / 64, s = run / FEA_Q_WAVES, wv = (s & 1) ? FEA_Q_WAVES - 1 - (run % FEA_Q_WAVES) : (run % FEA_Q_WAVES);
         const int slot = s * FEA_Q_THREADS + wv * 64 + (i & 63);           // thread wv*64 + i%64, block slot s
         Lc.tpos[slot] = tp[order[i]];
         Lc.lists[slot].swap(lists[order[i]]);
         const int len = (int)Lc.lists[slot].size();
         if (len > 250) too_long = true;
-        h.cnt[4 * s + wv] = (unsigned char)std::max((int)h.cnt[4 * s + wv], std::min(len, 250));
+        h.cnt[FEA_Q_WAVES * s + wv] = (unsigned char)std::max((int)h.cnt[FEA_Q_WAVES * s + wv], std::min(len, 250));
         h.sw[s] = (unsigned char)std::max((int)h.sw[s], (std::min(len, 250) + 1) / 2);
       }
       if (too_long) { bad[p] = 1; continue; }

@@ -374,7 +374,7 @@ int launch_assemble_gather(feahip_ctx *c, bool doK, bool doF)
   static int ncu_of[64];
   int &ncu = ncu_of[c->device & 63];
   if (ncu <= 0) { hipDeviceProp_t p; ncu = (hipGetDeviceProperties(&p, c->device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
-  const int run_len = run_env ? run_env : (FEA_G_BIG ? std::max(1, (c->ngchunks + 2 * ncu - 1) / (2 * ncu)) : 16);
+  const int run_len = run_env ? run_env : (FEA_G_BIG == 1 ? std::max(1, (c->ngchunks + 2 * ncu - 1) / (2 * ncu)) : 16);
   const int nruns = (c->ngchunks + run_len - 1) / run_len;
   const dim3 grid((nruns + 7) & ~7), blk(FEA_G_THREADS);
   // LDS: coordinates (48 bytes per node slot) | element records, later the K tile (+1 double of alignment slack) and the residual partials

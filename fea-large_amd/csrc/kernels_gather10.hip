@@ -199,7 +199,7 @@ __device__ __forceinline__ void t_visit(const unsigned char *sRb, const double *
 // TLDS: the shape-gradient table in LDS (rules of up to T_GLDS points); the 27-point rule reads it through the cache -- 8.6 KB
 // more LDS would cost the second workgroup of a CU
 template <int NPE, bool DOK, bool DOF, bool TLDS>
-__global__ __launch_bounds__(FEA_Q_THREADS, 2)
+__global__ __launch_bounds__(FEA_Q_THREADS, FEA_Q_THREADS / 128)
 void k_assemble_gather10(G10Args A, int run_len)
 {
   constexpr int T_REC = T_RECD(NPE);
@@ -244,11 +244,11 @@ void k_assemble_gather10(G10Args A, int run_len)
     {
       int row = 0;
 #pragma unroll
-      for (int s = 0; s < FEA_Q_SLOTS; ++s) { cnt[s] = hp->cnt[4 * s + wv]; srow[s] = row; row += hp->sw[s]; }
+      for (int s = 0; s < FEA_Q_SLOTS; ++s) { cnt[s] = hp->cnt[FEA_Q_WAVES * s + wv]; srow[s] = row; row += hp->sw[s]; }
     }
     // ---- stage the chunk: row table; this thread's element, block positions and lists
     // expand: `parts` threads per element, thread xp of them takes the nodes xp, xp + parts, ...
-    const int parts = nelem <= 64 ? 4 : (nelem <= 85 ? 3 : 2);
+    const int parts = 4 * nelem <= FEA_Q_THREADS ? 4 : (3 * nelem <= FEA_Q_THREADS ? 3 : 2);
     const int xe = parts == 4 ? t >> 2 : (parts == 3 ? (int)(((unsigned)t * 21846u) >> 16) : t >> 1), xp = t - xe * parts;
     const bool xact = xe < nelem;
     const double2 *srec = reinterpret_cast<const double2 *>(
@@ -430,7 +430,7 @@ void k_assemble_gather10(G10Args A, int run_len)
   }
 #ifdef FEAHIP_DEBUG
   if (A.stamps && (t & 63) == 0) {
-    unsigned long long *o = A.stamps + ((size_t)ridx * 4 + (t >> 6)) * 8;
+    unsigned long long *o = A.stamps + ((size_t)ridx * FEA_Q_WAVES + (t >> 6)) * 8;
     for (int i = 0; i < 8; ++i) o[i] = qa[i];
   }
 #endif
@@ -524,11 +524,11 @@ int launch_assemble_gather10(feahip_ctx *c, bool doK, bool doF)
     static int calls = 0;
     if (++calls == 8) {
       (void)hipStreamSynchronize(c->stream);
-      std::vector<unsigned long long> h((size_t)c->ngchunks * 32);
+      std::vector<unsigned long long> h((size_t)c->ngchunks * 8 * FEA_Q_WAVES);
       (void)hipMemcpy(h.data(), A.stamps, h.size() * 8, hipMemcpyDeviceToHost);
       for (int w = 0; w < 4; ++w) {
         double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < nruns; ++i) for (int q = 0; q < 8; ++q) sum[q] += (double)h[((size_t)i * 4 + w) * 8 + q];
+        for (int i = 0; i < nruns; ++i) for (int q = 0; q < 8; ++q) sum[q] += (double)h[((size_t)i * FEA_Q_WAVES + w) * 8 + q];
         fprintf(stderr, "[gather10 stamps wave %d, per chunk] stage %.0f  state wait %.0f  expand %.0f  barrier %.0f  gather %.0f  barrier %.0f  partials+barrier %.0f  write-out %.0f\n",
                 w, sum[0] / c->ngchunks, sum[7] / c->ngchunks, sum[1] / c->ngchunks, sum[2] / c->ngchunks, sum[3] / c->ngchunks, sum[4] / c->ngchunks, sum[5] / c->ngchunks, sum[6] / c->ngchunks);
       }
