@@ -250,24 +250,85 @@ __device__ __forceinline__ double lintet_record_nh(const double (&x)[4][3], cons
   return detJ;
 }
 
-// any model through the general state of fem_device.h (A5)
+// The same record for the A5 model (fea_model.c:26-77, 110-127): S = (lambda tr(C) I + 2 mu C)/J with C = (F'F - I)/2,
+// sigma = F S F'.  With B = F F' = J^2 adj(Fi) adj(Fi)' (Fi = F^-1 as above, J = 1/det Fi) this is
+//   sigma = (lambda I1 B + mu (B B - B))/J,  I1 = (tr B - 3)/2,   l1 = lambda/J, m1 = mu/J
+// -- symmetric 3x3 products only, no F, no general inverse: what keeps the record inside the register budget of a
+// 1024-thread workgroup (the general state of fem_device.h spilled 76 bytes per lane there).
 template <bool DOK>
-__device__ __forceinline__ double lintet_record_any(const double (&xe)[4][3], const double (&Xe)[4][3], const ElemTable *tab,
-                                                    int model, double lambda, double mu, double *R)
+__device__ __forceinline__ double lintet_record_a5(const double (&x)[4][3], const double (&X)[4][3], double w,
+                                                   double lambda, double mu, double *R)
 {
-  GPState<4> s;
-  gp_state<4, true, false>(xe, Xe, tab, 0, model, lambda, mu, s);
-  const double vm = s.vol * s.m1;
+  double J[3][3], D[3][3];
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
+  for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const double sg = s.vol * (s.sig[i][0] * s.g[b][0] + s.sig[i][1] * s.g[b][1] + s.sig[i][2] * s.g[b][2]);
-      if (DOK) { R[b * 3 + i] = s.g[b][i]; R[12 + b * 3 + i] = __dadd_rn(__dmul_rn(vm, s.g[b][i]), sg); }
-      else R[b * 3 + i] = sg;
-    }
-  if (DOK) { R[24] = s.vol * s.l1; R[25] = vm; }
-  return s.detJ;
+    for (int j = 0; j < 3; ++j) { J[i][j] = x[i + 1][j] - x[0][j]; D[i][j] = X[i + 1][j] - X[0][j]; }
+  double c[3][3];
+  c[0][0] = J[1][1] * J[2][2] - J[1][2] * J[2][1]; c[0][1] = J[1][2] * J[2][0] - J[1][0] * J[2][2]; c[0][2] = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+  c[1][0] = J[0][2] * J[2][1] - J[0][1] * J[2][2]; c[1][1] = J[0][0] * J[2][2] - J[0][2] * J[2][0]; c[1][2] = J[0][1] * J[2][0] - J[0][0] * J[2][1];
+  c[2][0] = J[0][1] * J[1][2] - J[0][2] * J[1][1]; c[2][1] = J[0][2] * J[1][0] - J[0][0] * J[1][2]; c[2][2] = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+  const double detJ = J[0][0] * c[0][0] + J[0][1] * c[0][1] + J[0][2] * c[0][2];
+  const double id = fd_rcp(detJ);
+  double g[4][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g[k + 1][i] = c[k][i] * id;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) g[0][i] = -((g[1][i] + g[2][i]) + g[3][i]);
+  double Fi[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Fi[i][j] = g[1][j] * D[0][i] + g[2][j] * D[1][i] + g[3][j] * D[2][i];
+  // adj(Fi): F = adj(Fi) / det(Fi)
+  double A[3][3];
+  A[0][0] = Fi[1][1] * Fi[2][2] - Fi[1][2] * Fi[2][1]; A[0][1] = Fi[0][2] * Fi[2][1] - Fi[0][1] * Fi[2][2]; A[0][2] = Fi[0][1] * Fi[1][2] - Fi[0][2] * Fi[1][1];
+  A[1][0] = Fi[1][2] * Fi[2][0] - Fi[1][0] * Fi[2][2]; A[1][1] = Fi[0][0] * Fi[2][2] - Fi[0][2] * Fi[2][0]; A[1][2] = Fi[0][2] * Fi[1][0] - Fi[0][0] * Fi[1][2];
+  A[2][0] = Fi[1][0] * Fi[2][1] - Fi[1][1] * Fi[2][0]; A[2][1] = Fi[0][1] * Fi[2][0] - Fi[0][0] * Fi[2][1]; A[2][2] = Fi[0][0] * Fi[1][1] - Fi[0][1] * Fi[1][0];
+  const double detFi = Fi[0][0] * A[0][0] + Fi[0][1] * A[1][0] + Fi[0][2] * A[2][0];
+  const double Jd = fd_rcp(detFi), J2 = Jd * Jd;
+  // B = F F' (symmetric: 00 01 02 11 12 22)
+  const double b00 = J2 * (A[0][0] * A[0][0] + A[0][1] * A[0][1] + A[0][2] * A[0][2]);
+  const double b01 = J2 * (A[0][0] * A[1][0] + A[0][1] * A[1][1] + A[0][2] * A[1][2]);
+  const double b02 = J2 * (A[0][0] * A[2][0] + A[0][1] * A[2][1] + A[0][2] * A[2][2]);
+  const double b11 = J2 * (A[1][0] * A[1][0] + A[1][1] * A[1][1] + A[1][2] * A[1][2]);
+  const double b12 = J2 * (A[1][0] * A[2][0] + A[1][1] * A[2][1] + A[1][2] * A[2][2]);
+  const double b22 = J2 * (A[2][0] * A[2][0] + A[2][1] * A[2][1] + A[2][2] * A[2][2]);
+  const double I1 = 0.5 * ((b00 + b11 + b22) - 3.0);
+  const double vol = w * fabs(detJ);
+  const double vd = vol * detFi;                          // vol / J
+  const double a_ = vd * (lambda * I1 - mu), m_ = vd * mu; // vol sigma = a_ B + m_ B B
+  double S[3][3];
+  S[0][0] = a_ * b00 + m_ * (b00 * b00 + b01 * b01 + b02 * b02);
+  S[1][1] = a_ * b11 + m_ * (b01 * b01 + b11 * b11 + b12 * b12);
+  S[2][2] = a_ * b22 + m_ * (b02 * b02 + b12 * b12 + b22 * b22);
+  S[0][1] = S[1][0] = a_ * b01 + m_ * (b00 * b01 + b01 * b11 + b02 * b12);
+  S[0][2] = S[2][0] = a_ * b02 + m_ * (b00 * b02 + b01 * b12 + b02 * b22);
+  S[1][2] = S[2][1] = a_ * b12 + m_ * (b01 * b02 + b11 * b12 + b12 * b22);
+  const double vm = vd * mu;                              // vol m1, m1 = mu / J
+  if (DOK) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) R[b * 3 + i] = g[b][i];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        R[12 + b * 3 + i] = __dadd_rn(__dmul_rn(vm, g[b][i]), S[i][0] * g[b][0] + S[i][1] * g[b][1] + S[i][2] * g[b][2]);
+    R[24] = vd * lambda;                                  // vol lambda / J
+    R[25] = vm;
+  } else {
+#pragma unroll
+    for (int b = 1; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) R[b * 3 + i] = S[i][0] * g[b][0] + S[i][1] * g[b][1] + S[i][2] * g[b][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) R[i] = -((R[3 + i] + R[6 + i]) + R[9 + i]);
+  }
+  return detJ;
 }
 
 // workgroup barrier that orders LDS only: __syncthreads() would also drain every global load and store in flight

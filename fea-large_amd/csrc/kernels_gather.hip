@@ -130,7 +130,7 @@ void k_assemble_gather(GatherArgs A, int run_len)
       double detJ;
       if (G_ABL(8)) { detJ = 1.0; for (int q = 0; q < REC; ++q) R[q] = xe[q & 3][q % 3] + Xe[(q >> 2) & 3][q % 3]; }
       else detJ = NH ? lintet_record_nh<DOK>(xe, Xe, gauss_w, A.lambda, A.mu, R)
-                     : lintet_record_any<DOK>(xe, Xe, A.tab, A.model, A.lambda, A.mu, R);
+                     : lintet_record_a5<DOK>(xe, Xe, gauss_w, A.lambda, A.mu, R);
       if (!(detJ > 0.0)) {                             // rare, kept off the fast path
         if (DOK) {                                     // counted by the chunk that owns its lowest-numbered node
           const int *gn = reinterpret_cast<const int *>(rec + A.lay.o_nodes);
