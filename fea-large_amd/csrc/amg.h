@@ -30,6 +30,7 @@ struct AmgLevel {
   int *rowptr = nullptr, *colidx = nullptr, *diag = nullptr, *chunk = nullptr;
   double *K = nullptr, *minv = nullptr;
   float *K32 = nullptr;                  // coarse levels may store their matrix in single precision instead (K null)
+  unsigned short *K16 = nullptr;         // level 0: bfloat16 copy of the context's K for the smoother's products
   double omega = 0.6;
   uint8_t *type = nullptr;               // [N] 0 = translation row, 1 = rotation row; null on level 0 (all 0)
   // to the next (coarser) level
@@ -46,15 +47,16 @@ struct AmgLevel {
 
 struct AmgHierarchy {
   std::vector<AmgLevel> lv;
-  int coarse_sweeps = 12;
+  int coarse_sweeps = 2;                 // damped Jacobi sweeps on the coarsest level (amg_setup.cpp: why so few)
   int gamma_from = 0;                    // first level whose coarse correction is repeated `gamma` times
   int gamma = 2;                         // coarse corrections per level below the finest (2 = W-cycle)
   double over = 2.0;                     // over-correction of the prolongated correction (<= 2 keeps the cycle SPD);
                                          // 10M-tet block, PCG to 1e-14: V-cycle 274 iterations (over 1.5), W-cycle below the
                                          // finest level 150, W-cycle on every level 94 (339 ms against 1 704 ms block-Jacobi)
   bool numeric_valid = false;
-  bool fine_f32 = true;                  // the smoother of level 0 multiplies with a float copy of K (FEAHIP_AMG_F32=1: with K
-                                         // itself): 94 iterations either way on the 10M-tet block, 20 % less time, +4 bytes per value
+  int fine_bits = 16;                    // the smoother of level 0 multiplies with a copy of K in bfloat16 (FEAHIP_AMG_FINE_BITS=32:
+                                         // float, 64: K itself): 95 iterations each way on the 10M-tet block (float 16 in between
+                                         // 88); per iteration 2.7 ms with the float copy, 3.2 with K, +2 bytes per value
   bool coarse_f32 = true;                // coarse matrices stored in single precision (FEAHIP_AMG_F32=0: double): the
                                          // preconditioner stays a fixed linear operator, vectors and arithmetic are double;
                                          // same 94 iterations on the 10M-tet block, 7 % less time, half the memory

@@ -10,6 +10,8 @@ void enq_spmv_jacobi(hipStream_t stream, int nchunks, const int *chunk, const in
                      const float *K32, const double *xin, double *xout, const double *r, const double *minv, double omega);
 void enq_spmv_arrays_f32(hipStream_t stream, int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx,
                          const float *K, const double *xv, double *yv);
+void enq_spmv_arrays_bf16(hipStream_t stream, int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx,
+                          const unsigned short *K, const double *xv, double *yv);
 
 // ---------------------------------------------------------------------------
 // kernels
@@ -207,10 +209,23 @@ __global__ void k_fill_pattern(int t0, int t1, int n, double *v)
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) v[t] = (t >= t0 && t < t1) ? 1.0 + 0.37 * (double)((t * 2654435761u) >> 24) / 256.0 : 0.0;   // fixed pseudo-random start
 }
-// single-precision copy of the fine matrix for the smoother of level 0 (the CG itself multiplies with the double one)
+// copies of the fine matrix for the smoother of level 0 (the CG itself multiplies with the double one): float, or
+// bfloat16 rounded to nearest even from the float
 __global__ void k_to_f32(size_t n, const double *src, float *dst)
 {
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) dst[t] = (float)src[t];
+}
+// (n rows of three values -> rows of four: three values and a zero pad, 8 bytes)
+__global__ void k_to_bf16(size_t nrows3, const double *src, unsigned short *dst)
+{
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nrows3; t += (size_t)gridDim.x * blockDim.x) {
+    unsigned short o[4] = {0, 0, 0, 0};
+    for (int j = 0; j < 3; ++j) {
+      const unsigned u = __float_as_uint((float)src[t * 3 + j]);
+      o[j] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    }
+    reinterpret_cast<uint2 *>(dst)[t] = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2]);
+  }
 }
 
 // |v|^2 in two stages with a fixed grid and order (deterministic)
@@ -281,7 +296,8 @@ int amg_create(feahip_ctx *c)
   c->amg = h;
   h->row0 = c->row0; h->row1 = c->row1;
   { const char *e = getenv("FEAHIP_AMG_GAMMA"); if (e) h->gamma = atoi(e); }
-  { const char *e = getenv("FEAHIP_AMG_F32"); h->coarse_f32 = !(e && atoi(e) == 0); h->fine_f32 = !(e && atoi(e) != 2); }
+  { const char *e = getenv("FEAHIP_AMG_F32"); h->coarse_f32 = !(e && atoi(e) == 0); }
+  { const char *e = getenv("FEAHIP_AMG_FINE_BITS"); if (e && (atoi(e) == 32 || atoi(e) == 64)) h->fine_bits = atoi(e); }
   { const char *e = getenv("FEAHIP_AMG_OVER"); if (e) h->over = atof(e); }
   { const char *e = getenv("FEAHIP_AMG_GAMMA_FROM"); if (e) h->gamma_from = atoi(e); }
   { const char *e = getenv("FEAHIP_AMG_SWEEPS"); if (e) h->coarse_sweeps = atoi(e); }
@@ -294,10 +310,14 @@ int amg_create(feahip_ctx *c)
     if (l == 0) {
       L.rowptr = c->d_rowptr; L.colidx = c->d_colidx; L.diag = c->d_diag; L.chunk = c->d_chunk; L.K = c->d_K;
       L.nchunks = c->nchunks;
-      if (h->coarse_f32 && h->fine_f32) {
+      if (h->fine_bits == 32) {
         FEA_HIP_CHECK(c, hipMalloc((void **)&L.K32, sizeof(float) * ((size_t)c->nnzb * 9 + 4)));
         FEA_HIP_CHECK(c, hipMemset(L.K32, 0, sizeof(float) * ((size_t)c->nnzb * 9 + 4)));
         h->bytes += (long long)(sizeof(float) * (size_t)c->nnzb * 9);
+      } else if (h->fine_bits == 16) {
+        FEA_HIP_CHECK(c, hipMalloc((void **)&L.K16, sizeof(unsigned short) * ((size_t)c->nnzb * 12 + 8)));
+        FEA_HIP_CHECK(c, hipMemset(L.K16, 0, sizeof(unsigned short) * ((size_t)c->nnzb * 12 + 8)));
+        h->bytes += (long long)(sizeof(unsigned short) * (size_t)c->nnzb * 12);
       }
     } else {
       L.owns_matrix = true;
@@ -340,7 +360,7 @@ void amg_destroy(feahip_ctx *c)
     void *own[] = {L.minv, L.agg, L.doff, L.aptr, L.anodes, L.cbptr, L.cblist, L.prow, L.cbrow, L.r, L.x, L.y, L.type};
     for (void *p : own) if (p) (void)hipFree(p);
     if (L.owns_matrix) { void *m[] = {L.rowptr, L.colidx, L.diag, L.chunk, L.K, L.K32}; for (void *p : m) if (p) (void)hipFree(p); }
-    else if (L.K32) (void)hipFree(L.K32);
+    else { if (L.K32) (void)hipFree(L.K32); if (L.K16) (void)hipFree(L.K16); }
   }
   if (h->d_z) (void)hipFree(h->d_z);
   if (h->d_pw) (void)hipFree(h->d_pw);
@@ -364,7 +384,8 @@ static LevelRange level_range(feahip_ctx *c, int l)
 
 static void level_spmv(feahip_ctx *c, const AmgLevel &L, const LevelRange &R, const double *x, double *y)
 {
-  if (L.K32) enq_spmv_arrays_f32(c->stream, R.ch0, R.nch, L.chunk, L.rowptr, L.colidx, L.K32, x, y);
+  if (L.K16) enq_spmv_arrays_bf16(c->stream, R.ch0, R.nch, L.chunk, L.rowptr, L.colidx, L.K16, x, y);
+  else if (L.K32) enq_spmv_arrays_f32(c->stream, R.ch0, R.nch, L.chunk, L.rowptr, L.colidx, L.K32, x, y);
   else enq_spmv_arrays(c->stream, R.ch0, R.nch, L.chunk, L.rowptr, L.colidx, L.K, x, y);
 }
 
@@ -376,9 +397,10 @@ static int amg_numeric(feahip_ctx *c)
   for (int l = 0; l < nl; ++l) {
     AmgLevel &L = h->lv[l];
     const LevelRange R = level_range(c, l);
-    if (l == 0 && L.K32) {                               // the rank's rows only
+    if (l == 0 && (L.K32 || L.K16)) {                    // the rank's rows only
       const size_t q0 = (size_t)c->h_rowptr[(size_t)h->row0] * 9, q1 = (size_t)c->h_rowptr[(size_t)h->row1] * 9;
-      hipLaunchKernelGGL(k_to_f32, dim3(4096), dim3(256), 0, c->stream, q1 - q0, (const double *)L.K + q0, L.K32 + q0);
+      if (L.K16) hipLaunchKernelGGL(k_to_bf16, dim3(4096), dim3(256), 0, c->stream, (q1 - q0) / 3, (const double *)L.K + q0, L.K16 + q0 / 3 * 4);
+      else hipLaunchKernelGGL(k_to_f32, dim3(4096), dim3(256), 0, c->stream, q1 - q0, (const double *)L.K + q0, L.K32 + q0);
     }
     if (l > 0 && L.K32) hipLaunchKernelGGL(k_block_inverse<float>, GROWS(R), R.a0, R.a1, L.diag, L.K32, L.minv);
     else hipLaunchKernelGGL(k_block_inverse<double>, GROWS(R), R.a0, R.a1, L.diag, L.K, L.minv);

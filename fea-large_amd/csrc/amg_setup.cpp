@@ -1,6 +1,7 @@
 // amg_setup.cpp -- topology and geometry of the aggregation hierarchy, host, once.
 #include "amg.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -112,6 +113,12 @@ static bool build_levels(const std::vector<int> &rowptr0, const std::vector<int>
                          std::vector<HostAmgLevel> &out)
 {
   out.clear();
+  // block rows of the level the hierarchy stops at (FEAHIP_AMG_COARSEST: tuning).  The W-cycle's over-correction counts on
+  // inexact coarse solves, and what serves it best is depth, not sweeps: 10M-tet block, stop at 1 500 rows with 12
+  // Jacobi sweeps there (4 levels) 95 CG iterations / 0.243 s per Newton iteration, 48 sweeps 96 iterations, stop at 200
+  // rows (5 levels) with 12 sweeps 77 / 0.232 s, with 2 sweeps 79 / 0.196 s
+  int coarsest_rows = 200;
+  if (const char *e = getenv("FEAHIP_AMG_COARSEST")) coarsest_rows = std::max(2, atoi(e));
   HostAmgLevel L;
   L.N = (int)rowptr0.size() - 1;
   L.S = L.N;
@@ -123,7 +130,7 @@ static bool build_levels(const std::vector<int> &rowptr0, const std::vector<int>
     const int N = L.N, S = L.S;
     const bool paired = (N == 2 * S);                                      // false only on level 0
     finish_pattern(L);
-    if (N <= 1500 || out.size() >= 6) { L.Sc = 0; out.push_back(L); break; }
+    if (N <= coarsest_rows || out.size() >= 6) { L.Sc = 0; out.push_back(L); break; }
     int nagg = 0;
     std::vector<int> sagg;
     aggregate(S, sg_rowptr, sg_colidx, sagg, nagg);

@@ -179,6 +179,28 @@ int launch_update_nodes_solution(feahip_ctx *c, const double *d_uv)
 // (the 72-byte blocks of neighbouring lanes share cache lines, so the nine
 // strided loads of a wave hit L1 after the first touch).
 // ------------------------------------------------------------------------
+// nine values of block kk as doubles.  bf16_t: the block is stored as three rows of four bfloat16 (three values and a
+// pad: 24 bytes, three 8-byte loads instead of nine 2-byte ones)
+struct bf16_t { unsigned short v[4]; };
+template <class TK>
+__device__ __forceinline__ void load_block9(const TK *K, size_t kk, double (&v)[9])
+{
+  const TK *vp = K + kk * 9;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) v[q] = (double)vp[q];
+}
+template <>
+__device__ __forceinline__ void load_block9<bf16_t>(const bf16_t *K, size_t kk, double (&v)[9])
+{
+  const uint2 *vp = reinterpret_cast<const uint2 *>(K) + kk * 3;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const uint2 w = vp[i];
+    v[3 * i] = (double)__uint_as_float(w.x << 16);
+    v[3 * i + 1] = (double)__uint_as_float(w.x & 0xFFFF0000u);
+    v[3 * i + 2] = (double)__uint_as_float(w.y << 16);
+  }
+}
 template <class TK>
 __device__ __forceinline__ void spmv_body(int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx, const TK *K,
                                           const double *x, double *y, const double *dotwith, double *part, const int *flag)
@@ -199,11 +221,12 @@ __device__ __forceinline__ void spmv_body(int chunk0, int nchunks, const int *ch
       double a0 = 0, a1 = 0, a2 = 0;
       for (int k = lane; k < nb; k += 64) {
         const int col = colidx[b0 + k];
-        const TK *vp = K + (size_t)(b0 + k) * 9;
+        double vp[9];
+        load_block9<TK>(K, (size_t)(b0 + k), vp);
         const double x0 = x[(size_t)col * 3], x1 = x[(size_t)col * 3 + 1], x2 = x[(size_t)col * 3 + 2];
-        a0 += (double)vp[0] * x0 + (double)vp[1] * x1 + (double)vp[2] * x2;
-        a1 += (double)vp[3] * x0 + (double)vp[4] * x1 + (double)vp[5] * x2;
-        a2 += (double)vp[6] * x0 + (double)vp[7] * x1 + (double)vp[8] * x2;
+        a0 += vp[0] * x0 + vp[1] * x1 + vp[2] * x2;
+        a1 += vp[3] * x0 + vp[4] * x1 + vp[5] * x2;
+        a2 += vp[6] * x0 + vp[7] * x1 + vp[8] * x2;
       }
       a0 = wave_sum_all(a0); a1 = wave_sum_all(a1); a2 = wave_sum_all(a2);
       if (lane < 3) {
@@ -220,9 +243,7 @@ __device__ __forceinline__ void spmv_body(int chunk0, int nchunks, const int *ch
       const bool on = k < nb;
       const int kk = on ? b0 + k : b0;
       const int col = colidx[kk];
-      const TK *vp = K + (size_t)kk * 9;
-#pragma unroll
-      for (int q = 0; q < 9; ++q) v[h][q] = (double)vp[q];
+      load_block9<TK>(K, (size_t)kk, v[h]);
 #pragma unroll
       for (int i = 0; i < 3; ++i) xv[h][i] = x[(size_t)col * 3 + i];
     }
@@ -266,6 +287,15 @@ void k_spmv_f32(int chunk0, int nchunks, const int *chunk, const int *rowptr, co
                 const double *x, double *y)
 {
   spmv_body<float>(chunk0, nchunks, chunk, rowptr, colidx, K, x, y, (const double *)nullptr, (double *)nullptr, (const int *)nullptr);
+}
+
+// ... and in bfloat16 (the smoother of level 0: the 16 high bits of the float, a third of the double matrix's bytes with
+// the index; 10M-tet block: the same 95 CG iterations as with the float copy)
+__global__ __launch_bounds__(256)
+void k_spmv_bf16(int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx, const bf16_t *K,
+                 const double *x, double *y)
+{
+  spmv_body<bf16_t>(chunk0, nchunks, chunk, rowptr, colidx, K, x, y, (const double *)nullptr, (double *)nullptr, (const int *)nullptr);
 }
 
 // One damped block-Jacobi sweep fused with its product: xout = xin + omega D^-1 (r - K xin).  The product is the
@@ -1090,6 +1120,15 @@ void enq_spmv_arrays_f32(hipStream_t stream, int chunk0, int nchunks, const int 
   int g = (nchunks + FEA_WAVES_PER_WG - 1) / FEA_WAVES_PER_WG;
   g = g < FEA_RED_BLOCKS ? (g > 0 ? g : 1) : FEA_RED_BLOCKS;
   hipLaunchKernelGGL(k_spmv_f32, dim3(g), dim3(256), 0, stream, chunk0, nchunks, chunk, rowptr, colidx, K, xv, yv);
+}
+
+void enq_spmv_arrays_bf16(hipStream_t stream, int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx,
+                          const unsigned short *K, const double *xv, double *yv)
+{
+  int g = (nchunks + FEA_WAVES_PER_WG - 1) / FEA_WAVES_PER_WG;
+  g = g < FEA_RED_BLOCKS ? (g > 0 ? g : 1) : FEA_RED_BLOCKS;
+  hipLaunchKernelGGL(k_spmv_bf16, dim3(g), dim3(256), 0, stream, chunk0, nchunks, chunk, rowptr, colidx,
+                     reinterpret_cast<const bf16_t *>(K), xv, yv);
 }
 
 void enq_spmv_arrays(hipStream_t stream, int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx,

@@ -543,11 +543,19 @@ def test_feasolver_hip_command_line(decks_dir, tmp_path):
     last = [i for i, l in enumerate(msh) if l == "$NodeData"][-1]
     row = msh[last + 9 + top].split()
     assert int(row[0]) == top + 1 and float(row[2]) == pytest.approx(0.1, abs=1e-6)
-    # the one extra option: on this 737-node deck there is nothing to coarsen -- asked for and unavailable is an error
-    # (exit code 1, message), never a quiet run with another preconditioner
+    # the one extra option: the same run with the multigrid preconditioner (737 nodes: two levels) -- same Newton path
     res2 = subprocess.run([exe, str(deckfile), "--multigrid"], capture_output=True, text=True, timeout=300)
-    assert res2.returncode == 1 and "--multigrid" in res2.stderr and "multigrid" in res2.stderr
-    assert res2.stdout.count("Newton iteration") == 0                  # no quiet run with another preconditioner
+    assert res2.returncode == 0, res2.stderr
+    assert res2.stdout.count("Newton iteration") == 25
+    tol2 = [float(v) for v in re.findall(r"Tolerance <X,R> = (\S+)", res2.stdout)]
+    assert tol2[0] == pytest.approx(tol[0], rel=1e-9) and abs(tol2[12]) < 1e-6 <= abs(tol2[11])
+    # on a 117-node bar there is nothing to coarsen -- asked for and unavailable is an error (exit code 1, message),
+    # never a quiet run with another preconditioner
+    tiny = tmp_path / "tiny.sexp"
+    mesh.bar_deck(n=2).save(str(tiny))
+    res3 = subprocess.run([exe, str(tiny), "--multigrid"], capture_output=True, text=True, timeout=300)
+    assert res3.returncode == 1 and "--multigrid" in res3.stderr and "multigrid" in res3.stderr
+    assert res3.stdout.count("Newton iteration") == 0                  # no quiet run with another preconditioner
 
 
 def test_node_with_more_neighbours_than_the_spmv_tile():
