@@ -48,6 +48,7 @@ struct AmgLevel {
 struct AmgHierarchy {
   std::vector<AmgLevel> lv;
   int coarse_sweeps = 2;                 // damped Jacobi sweeps on the coarsest level (amg_setup.cpp: why so few)
+  int tail_from = -1;                    // first level of the subtree the one-workgroup kernel runs (amg.hip: k_amg_tail); -1: none
   int gamma_from = 0;                    // first level whose coarse correction is repeated `gamma` times
   int gamma = 2;                         // coarse corrections per level below the finest (2 = W-cycle)
   double over = 2.0;                     // over-correction of the prolongated correction (<= 2 keeps the cycle SPD);

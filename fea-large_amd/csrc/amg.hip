@@ -2,6 +2,7 @@
 #include "amg.h"
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 // from kernels_solve.hip
 void enq_spmv_arrays(hipStream_t stream, int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx,
@@ -27,23 +28,27 @@ __device__ __forceinline__ void cross3(const double *d, double a0, double a1, do
 {
   o0 = d[1] * a2 - d[2] * a1; o1 = d[2] * a0 - d[0] * a2; o2 = d[0] * a1 - d[1] * a0;
 }
+#define FEA_GAL_LANES 16                // lanes per aggregate pair
 template <class TIN, class TOUT>
-__global__ void k_galerkin(int npair, const int *prow, const int *crowptr, const int *cbptr, const int *cblist,
-                           const TIN *Kf, TOUT *Kc, const int *cbrow, const int *colidx_f, const uint8_t *type_f,
-                           const double *doff, const uint8_t *mask)
+__global__ __launch_bounds__(256)
+void k_galerkin(int npair, const int *prow, const int *crowptr, const int *cbptr, const int *cblist,
+                const TIN *Kf, TOUT *Kc, const int *cbrow, const int *colidx_f, const uint8_t *type_f,
+                const double *doff, const uint8_t *mask)
 {
-  // one thread per aggregate pair (I, J): its four coarse blocks (kind s of I, kind r of J) from one pass over the fine blocks
-  const int kp = blockIdx.x * blockDim.x + threadIdx.x;
-  if (kp >= npair) return;
-  const int I = prow[kp];
-  const int base0 = crowptr[2 * I], base1 = crowptr[2 * I + 1];
-  const int t = kp - base0 / 4;                 // position of J in I's aggregate row (the site graph has a quarter of the blocks)
+  // sixteen lanes per aggregate pair (I, J): lane s takes the fine blocks s, s + 16, ... of the pair's list, the four
+  // coarse blocks (kind s of I, kind r of J) meet in a fixed butterfly (deterministic).  One thread per pair read the
+  // 72-byte fine blocks one after the other: 9.7 ms for the 26M blocks of the 10M-tet block's level 0, 5.4 ms for the
+  // 60 000 pairs of the levels below (too few threads to fill the chip)
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int kp = gid / FEA_GAL_LANES, sub = gid % FEA_GAL_LANES;
+  const bool on = kp < npair;
   double acc[4][9];
 #pragma unroll
   for (int w = 0; w < 4; ++w)
 #pragma unroll
     for (int q = 0; q < 9; ++q) acc[w][q] = 0.0;
-  for (int p = cbptr[kp]; p < cbptr[kp + 1]; ++p) {
+  const int pb = on ? cbptr[kp] : 0, pe = on ? cbptr[kp + 1] : 0;
+  for (int p = pb + sub; p < pe; p += FEA_GAL_LANES) {
     const int q = cblist[p];
     const int i = cbrow[q], j = colidx_f[q];
     const int ti = type_f ? type_f[i] : 0, tj = type_f ? type_f[j] : 0;
@@ -86,12 +91,25 @@ __global__ void k_galerkin(int npair, const int *prow, const int *crowptr, const
       }
     }
   }
-  const int k[4] = {base0 + 2 * t, base0 + 2 * t + 1, base1 + 2 * t, base1 + 2 * t + 1};
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    TOUT *o = Kc + (size_t)k[w] * 9;
+  for (int w = 0; w < 4; ++w)
 #pragma unroll
-    for (int e = 0; e < 9; ++e) o[e] = (TOUT)acc[w][e];
+    for (int e = 0; e < 9; ++e) {
+      double v = acc[w][e];
+#pragma unroll
+      for (int o = FEA_GAL_LANES / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, FEA_GAL_LANES);
+      acc[w][e] = v;
+    }
+  if (!on || sub >= 4) return;
+  const int I = prow[kp];
+  const int base0 = crowptr[2 * I], base1 = crowptr[2 * I + 1];
+  const int t = kp - base0 / 4;                 // position of J in I's aggregate row (the site graph has a quarter of the blocks)
+  const int k = sub == 0 ? base0 + 2 * t : (sub == 1 ? base0 + 2 * t + 1 : (sub == 2 ? base1 + 2 * t : base1 + 2 * t + 1));
+  TOUT *o = Kc + (size_t)k * 9;
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    const double v = sub == 0 ? acc[0][e] : (sub == 1 ? acc[1][e] : (sub == 2 ? acc[2][e] : acc[3][e]));
+    o[e] = (TOUT)v;
   }
 }
 
@@ -258,6 +276,239 @@ __global__ void k_scale(int n, double f, double *v)
 }
 
 // ---------------------------------------------------------------------------
+// The small end of the hierarchy in ONE launch.  On the 10M-tet block the levels are 1 782 133 / 140 714 / 5 760 / 270 /
+// 10 block rows; a W-cycle visits level 3 eight times and level 4 sixteen times per application, and every step
+// there (a product over 5 260 blocks, a restriction to 5 aggregates) is a kernel that takes its 4-5 us of launch and
+// drain whatever it does: 120 of the ~250 launches of one application, 0.5 of its 2.5 ms.  k_amg_tail runs the
+// whole subtree below a level of at most FEA_TAIL_ROWS rows in one 1024-thread workgroup: the same steps in the same
+// order (smooth, product, restrict, recurse, prolong, product, smooth), __syncthreads between them, the vectors
+// where the separate kernels keep them (L2-resident), four lanes per block row in the products.
+// ---------------------------------------------------------------------------
+#define FEA_TAIL_T 1024
+#define FEA_TAIL_MAXL 4
+#define FEA_TAIL_ROWS 640             // 23 doubles of LDS per block row of the subtree: 640 + 64 + ... rows fit 160 KB
+#define FEA_TAIL_LDS_BLOCKS 1024       // a level with at most this many blocks keeps its (float) matrix and column indices in LDS too
+struct TailLevel {
+  int N, Nc, nagg, nnzb;
+  const int *rowptr, *colidx;
+  const float *K32; const double *K;
+  const double *minv; double omega;
+  const int *agg, *aptr, *anodes; const uint8_t *type; const double *doff;
+  double *r, *x;                        // global: the level the launch is entered at reads r here and leaves x here
+  int o_v;                              // LDS, in doubles: r at o_v, x at o_v + 3N, y at o_v + 6N
+  int o_K;                              // LDS, in doubles: nnzb * 9 floats, then nnzb column indices; -1: the matrix stays in L2
+  int o_aux;                            // LDS, in doubles: minv 9N, doff 3N, then ints rowptr N+1, agg N, type N, anodes N, aptr nagg+1
+};
+// the read-only per-row arrays of a level, staged in LDS by k_amg_tail (every step would otherwise pay an L2 round trip
+// for them: ~1 us x 19 steps per visit of the entry level)
+struct TailAux { const double *minv, *doff; const int *rowptr, *agg, *type, *anodes, *aptr; };
+__device__ __forceinline__ TailAux t_aux(const TailLevel &L, double *smem)
+{
+  TailAux a;
+  a.minv = smem + L.o_aux; a.doff = a.minv + 9 * L.N;
+  a.rowptr = reinterpret_cast<const int *>(a.doff + 3 * L.N); a.agg = a.rowptr + L.N + 1; a.type = a.agg + L.N;
+  a.anodes = a.type + L.N; a.aptr = a.anodes + L.N;
+  return a;
+}
+#define T_AUX_DOUBLES(N, nagg) (12 * (N) + (4 * (N) + (nagg) + 2 + 1) / 2 + 1)
+struct TailArgs {
+  TailLevel lv[FEA_TAIL_MAXL];
+  int gamma[FEA_TAIL_MAXL]; double over[FEA_TAIL_MAXL];
+  int nl, sweeps;
+};
+#define T_R(L) (smem + (L).o_v)
+#define T_X(L) (smem + (L).o_v + 3 * (L).N)
+#define T_Y(L) (smem + (L).o_v + 6 * (L).N)
+
+__device__ __forceinline__ void t_smooth_first(const TailLevel &L, double *smem)
+{
+  const double *r = T_R(L); double *x = T_X(L);
+  const TailAux X = t_aux(L, smem);
+  for (int a = threadIdx.x; a < L.N; a += FEA_TAIL_T) {
+    const double *m = X.minv + a * 9;
+    const double r0 = r[a * 3], r1 = r[a * 3 + 1], r2 = r[a * 3 + 2];
+    for (int i = 0; i < 3; ++i) x[a * 3 + i] = L.omega * (m[3 * i] * r0 + m[3 * i + 1] * r1 + m[3 * i + 2] * r2);
+  }
+}
+__device__ __forceinline__ void t_smooth_next(const TailLevel &L, double *smem)
+{
+  const double *r = T_R(L), *y = T_Y(L); double *x = T_X(L);
+  const TailAux X = t_aux(L, smem);
+  for (int a = threadIdx.x; a < L.N; a += FEA_TAIL_T) {
+    const double *m = X.minv + a * 9;
+    const double t0 = r[a * 3] - y[a * 3], t1 = r[a * 3 + 1] - y[a * 3 + 1], t2 = r[a * 3 + 2] - y[a * 3 + 2];
+    for (int i = 0; i < 3; ++i) x[a * 3 + i] += L.omega * (m[3 * i] * t0 + m[3 * i + 1] * t1 + m[3 * i + 2] * t2);
+  }
+}
+// y = K x: four neighbouring lanes share a block row, their partial sums meet in two shuffles (fixed order)
+__device__ __forceinline__ void t_spmv(const TailLevel &L, double *smem)
+{
+  const int t = threadIdx.x, sub = t & 3;
+  const double *x = T_X(L); double *y = T_Y(L);
+  const float *sK = L.o_K >= 0 ? reinterpret_cast<const float *>(smem + L.o_K) : (const float *)nullptr;
+  const int *sCol = sK ? reinterpret_cast<const int *>(sK + (size_t)L.nnzb * 9) : (const int *)nullptr;
+  const TailAux X = t_aux(L, smem);
+  for (int row0 = 0; row0 < L.N; row0 += FEA_TAIL_T / 4) {
+    const int row = row0 + (t >> 2);
+    double a0 = 0, a1 = 0, a2 = 0;
+    if (row < L.N) {
+      const int kb = X.rowptr[row], ke = X.rowptr[row + 1];
+      if (sK) {
+        for (int k = kb + sub; k < ke; k += 4) {
+          const int col = sCol[k];
+          const float *vp = sK + k * 9;
+          const double x0 = x[col * 3], x1 = x[col * 3 + 1], x2 = x[col * 3 + 2];
+          a0 += (double)vp[0] * x0 + (double)vp[1] * x1 + (double)vp[2] * x2;
+          a1 += (double)vp[3] * x0 + (double)vp[4] * x1 + (double)vp[5] * x2;
+          a2 += (double)vp[6] * x0 + (double)vp[7] * x1 + (double)vp[8] * x2;
+        }
+      } else if (L.K32) {
+        // from L2: the loads of eight blocks (a row of up to 32) are issued before the first is used -- one round trip
+        // per product instead of one per block
+        for (int k0 = kb + sub; k0 < ke; k0 += 32) {
+          float v[8][9]; int col[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u, kc = k < ke ? k : kb;
+            col[u] = L.colidx[kc];
+            const float *vp = L.K32 + (size_t)kc * 9;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) v[u][q] = vp[q];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (k0 + 4 * u < ke) {
+              const double x0 = x[col[u] * 3], x1 = x[col[u] * 3 + 1], x2 = x[col[u] * 3 + 2];
+              a0 += (double)v[u][0] * x0 + (double)v[u][1] * x1 + (double)v[u][2] * x2;
+              a1 += (double)v[u][3] * x0 + (double)v[u][4] * x1 + (double)v[u][5] * x2;
+              a2 += (double)v[u][6] * x0 + (double)v[u][7] * x1 + (double)v[u][8] * x2;
+            }
+          }
+        }
+      } else {
+        for (int k = kb + sub; k < ke; k += 4) {
+          const int col = L.colidx[k];
+          const double *vp = L.K + (size_t)k * 9;
+          const double x0 = x[col * 3], x1 = x[col * 3 + 1], x2 = x[col * 3 + 2];
+          a0 += vp[0] * x0 + vp[1] * x1 + vp[2] * x2;
+          a1 += vp[3] * x0 + vp[4] * x1 + vp[5] * x2;
+          a2 += vp[6] * x0 + vp[7] * x1 + vp[8] * x2;
+        }
+      }
+    }
+    a0 += __shfl_xor(a0, 1); a1 += __shfl_xor(a1, 1); a2 += __shfl_xor(a2, 1);
+    a0 += __shfl_xor(a0, 2); a1 += __shfl_xor(a1, 2); a2 += __shfl_xor(a2, 2);
+    if (row < L.N && sub < 3) y[row * 3 + sub] = sub == 0 ? a0 : (sub == 1 ? a1 : a2);
+  }
+}
+// r_c = P' (r - y), x += over P x_c: k_restrict / k_prolong for a workgroup
+__device__ __forceinline__ void t_restrict(const TailLevel &L, const TailLevel &C, double *smem)
+{
+  const double *r = T_R(L), *y = T_Y(L); double *rc = T_R(C);
+  const TailAux X = t_aux(L, smem);
+  for (int base = 0; base < L.nagg * 16; base += FEA_TAIL_T) {
+    const int gid = base + (int)threadIdx.x;
+    const int A = gid >> 4, sub = gid & 15;
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    if (A < L.nagg) {
+      for (int p = X.aptr[A] + sub; p < X.aptr[A + 1]; p += 16) {
+        const int i = X.anodes[p];
+        const int k = i * 3;
+        const double a0 = r[k] - y[k], a1 = r[k + 1] - y[k + 1], a2 = r[k + 2] - y[k + 2];
+        if (X.type[i]) { s[3] += a0; s[4] += a1; s[5] += a2; }
+        else {
+          s[0] += a0; s[1] += a1; s[2] += a2;
+          double m0, m1, m2;
+          cross3(X.doff + k, a0, a1, a2, m0, m1, m2);
+          s[3] += m0; s[4] += m1; s[5] += m2;
+        }
+      }
+    }
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+      for (int q = 0; q < 6; ++q) s[q] += __shfl_xor(s[q], w, 16);
+    if (A < L.nagg && sub < 6) rc[A * 6 + sub] = s[sub];
+  }
+}
+__device__ __forceinline__ void t_prolong(const TailLevel &L, const TailLevel &C, double over, double *smem)
+{
+  const double *xc = T_X(C); double *x = T_X(L);
+  const TailAux X = t_aux(L, smem);
+  for (int i = threadIdx.x; i < L.N; i += FEA_TAIL_T) {
+    const double *c6 = xc + X.agg[i] * 6;
+    const int k = i * 3;
+    double u0, u1, u2;
+    if (X.type[i]) { u0 = c6[3]; u1 = c6[4]; u2 = c6[5]; }
+    else {
+      const double dd[3] = {X.doff[k], X.doff[k + 1], X.doff[k + 2]};
+      u0 = c6[0] + (c6[4] * dd[2] - c6[5] * dd[1]);
+      u1 = c6[1] + (c6[5] * dd[0] - c6[3] * dd[2]);
+      u2 = c6[2] + (c6[3] * dd[1] - c6[4] * dd[0]);
+    }
+    x[k] += over * u0; x[k + 1] += over * u1; x[k + 2] += over * u2;
+  }
+}
+template <int D>
+__device__ void t_cycle(const TailArgs &A, int l, double *smem)
+{
+  const TailLevel &L = A.lv[l];
+  t_smooth_first(L, smem);
+  __syncthreads();
+  if (L.Nc == 0 || D == 0) {                            // the coarsest level: a few damped Jacobi sweeps
+    for (int s = 0; s < A.sweeps; ++s) { t_spmv(L, smem); __syncthreads(); t_smooth_next(L, smem); __syncthreads(); }
+    return;
+  }
+  for (int g = 0; g < A.gamma[l]; ++g) {
+    t_spmv(L, smem); __syncthreads();
+    t_restrict(L, A.lv[l + 1], smem); __syncthreads();
+    if (D > 0) t_cycle<(D > 0 ? D - 1 : 0)>(A, l + 1, smem);
+    t_prolong(L, A.lv[l + 1], A.over[l], smem); __syncthreads();
+  }
+  t_spmv(L, smem); __syncthreads();
+  t_smooth_next(L, smem); __syncthreads();
+}
+__global__ __launch_bounds__(FEA_TAIL_T)
+void k_amg_tail(TailArgs A)
+{
+  extern __shared__ __attribute__((aligned(16))) double tail_smem[];
+  double *smem = tail_smem;
+  for (int l = 0; l < A.nl; ++l) {                      // the levels' read-only arrays into LDS
+    const TailLevel &L = A.lv[l];
+    double *minv = smem + L.o_aux, *doff = minv + 9 * L.N;
+    int *rowptr = reinterpret_cast<int *>(doff + 3 * L.N), *agg = rowptr + L.N + 1, *type = agg + L.N, *anodes = type + L.N,
+        *aptr = anodes + L.N;
+    for (int i = threadIdx.x; i < 9 * L.N; i += FEA_TAIL_T) minv[i] = L.minv[i];
+    for (int i = threadIdx.x; i <= L.N; i += FEA_TAIL_T) rowptr[i] = L.rowptr[i];
+    if (L.Nc) {
+      for (int i = threadIdx.x; i < 3 * L.N; i += FEA_TAIL_T) doff[i] = L.doff[i];
+      for (int i = threadIdx.x; i < L.N; i += FEA_TAIL_T) { agg[i] = L.agg[i]; type[i] = (int)L.type[i]; anodes[i] = L.anodes[i]; }
+      for (int i = threadIdx.x; i <= L.nagg; i += FEA_TAIL_T) aptr[i] = L.aptr[i];
+    }
+  }
+  for (int l = 0; l < A.nl; ++l) {                      // small matrices too
+    const TailLevel &L = A.lv[l];
+    if (L.o_K < 0) continue;
+    float *sK = reinterpret_cast<float *>(smem + L.o_K);
+    int *sCol = reinterpret_cast<int *>(sK + (size_t)L.nnzb * 9);
+    for (int i = threadIdx.x; i < L.nnzb * 9; i += FEA_TAIL_T) sK[i] = L.K32[i];
+    for (int i = threadIdx.x; i < L.nnzb; i += FEA_TAIL_T) sCol[i] = L.colidx[i];
+  }
+  {
+    const TailLevel &L = A.lv[0];
+    double *r = T_R(L);
+    for (int i = threadIdx.x; i < 3 * L.N; i += FEA_TAIL_T) r[i] = L.r[i];
+  }
+  __syncthreads();
+  t_cycle<FEA_TAIL_MAXL - 1>(A, 0, smem);
+  {
+    const TailLevel &L = A.lv[0];
+    const double *x = T_X(L);
+    for (int i = threadIdx.x; i < 3 * L.N; i += FEA_TAIL_T) L.x[i] = x[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // hierarchy
 // ---------------------------------------------------------------------------
 static AmgHierarchy *H(feahip_ctx *c) { return reinterpret_cast<AmgHierarchy *>(c->amg); }
@@ -301,6 +552,17 @@ int amg_create(feahip_ctx *c)
   { const char *e = getenv("FEAHIP_AMG_OVER"); if (e) h->over = atof(e); }
   { const char *e = getenv("FEAHIP_AMG_GAMMA_FROM"); if (e) h->gamma_from = atoi(e); }
   { const char *e = getenv("FEAHIP_AMG_SWEEPS"); if (e) h->coarse_sweeps = atoi(e); }
+  // the levels the one-workgroup kernel takes: from the first level below the finest of at most FEA_TAIL_ROWS rows
+  h->tail_from = -1;
+  { const char *e = getenv("FEAHIP_AMG_TAIL");
+    if (!(e && atoi(e) == 0))
+      for (size_t l = 1; l < hl.size(); ++l)
+        if (hl[l].N <= FEA_TAIL_ROWS && (int)(hl.size() - l) <= FEA_TAIL_MAXL) {
+          long long need = 0;
+          for (size_t k = l; k < hl.size(); ++k) need += 9LL * hl[k].N + T_AUX_DOUBLES(hl[k].N, hl[k].Sc);
+          if (need * 8 <= 150 * 1024) h->tail_from = (int)l;
+          break;
+        } }
   int rc;
   h->lv.resize(hl.size());
   for (size_t l = 0; l < hl.size(); ++l) {
@@ -407,7 +669,7 @@ static int amg_numeric(feahip_ctx *c)
     if (L.Nc > 0) {
       AmgLevel &C = h->lv[l + 1];
       const uint8_t *gm = l == 0 ? c->d_dofmask : (const uint8_t *)nullptr;
-#define GALERKIN(TI, TO, KI, KO) hipLaunchKernelGGL((k_galerkin<TI, TO>), G256(C.nnzb / 4), C.nnzb / 4, L.prow, C.rowptr, L.cbptr, \
+#define GALERKIN(TI, TO, KI, KO) hipLaunchKernelGGL((k_galerkin<TI, TO>), G256((size_t)(C.nnzb / 4) * FEA_GAL_LANES), C.nnzb / 4, L.prow, C.rowptr, L.cbptr, \
                                                     L.cblist, KI, KO, L.cbrow, L.colidx, L.type, L.doff, gm)
       if (l > 0 && L.K32 && C.K32) GALERKIN(float, float, L.K32, C.K32);
       else if (C.K32) GALERKIN(double, float, L.K, C.K32);
@@ -445,6 +707,39 @@ static int amg_numeric(feahip_ctx *c)
 // (I - M K = S' (I - P B P' K)^gamma S), which is what CG needs.  The coarse
 // correction of plain aggregation is too small by a mesh-independent factor;
 // `over` scales it (over-correction).
+// the subtree from level tail_from down, in one launch: reads its r, leaves its x (what amg_cycle does for that level)
+static void launch_tail(feahip_ctx *c)
+{
+  AmgHierarchy *h = H(c);
+  TailArgs A;
+  memset(&A, 0, sizeof(A));
+  const int nl = (int)h->lv.size() - h->tail_from;
+  int off = 0;                                          // LDS layout, in doubles
+  for (int k = 0; k < nl; ++k) {
+    const int l = h->tail_from + k;
+    const AmgLevel &L = h->lv[l];
+    TailLevel &T = A.lv[k];
+    T.N = L.N; T.Nc = L.Nc; T.nagg = L.Nc / 2; T.nnzb = L.nnzb;
+    T.rowptr = L.rowptr; T.colidx = L.colidx; T.K32 = L.K32; T.K = L.K; T.minv = L.minv; T.omega = L.omega;
+    T.agg = L.agg; T.aptr = L.aptr; T.anodes = L.anodes; T.type = L.type; T.doff = L.doff;
+    T.r = L.r; T.x = L.x;
+    T.o_v = off; off += 9 * L.N;
+    T.o_aux = off; off += T_AUX_DOUBLES(L.N, L.Nc / 2);
+    T.o_K = -1;
+    A.gamma[k] = (l < h->gamma_from) ? 1 : h->gamma;
+    A.over[k] = A.gamma[k] >= 2 ? h->over : fmin(h->over, 1.0);
+  }
+  for (int k = nl - 1; k >= 0; --k) {                   // small matrices too, the most visited first, while they fit
+    const AmgLevel &L = h->lv[h->tail_from + k];
+    const int need = (L.nnzb * 10 + 1) / 2 + 1;
+    if (L.K32 && L.nnzb <= FEA_TAIL_LDS_BLOCKS && (off + need) * 8 <= 150 * 1024) { A.lv[k].o_K = off; off += need; }
+  }
+  A.nl = nl; A.sweeps = h->coarse_sweeps;
+  const int lds = off * 8;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_amg_tail), hipFuncAttributeMaxDynamicSharedMemorySize, lds);   // per device, per size
+  hipLaunchKernelGGL(k_amg_tail, dim3(1), dim3(FEA_TAIL_T), lds, c->stream, A);
+}
+
 static void amg_cycle(feahip_ctx *c, int l, const double *r, double *x, double *y)
 {
   AmgHierarchy *h = H(c);
@@ -473,7 +768,8 @@ static void amg_cycle(feahip_ctx *c, int l, const double *r, double *x, double *
   for (int g = 0; g < gamma; ++g) {
     level_spmv(c, L, R, x, y);
     hipLaunchKernelGGL(k_restrict, G256((C.N / 2) * 16), C.N / 2, L.aptr, L.anodes, L.type, L.doff, r, y, mask, C.r);
-    amg_cycle(c, l + 1, C.r, C.x, C.y);
+    if (l + 1 == h->tail_from) launch_tail(c);
+    else amg_cycle(c, l + 1, C.r, C.x, C.y);
     // over-correction only where the correction is applied twice: (I - aE)^2 >= 0 for any a <= 2, while a single
     // over-corrected step can flip the sign of the preconditioner on part of the spectrum (seen: 6 492 iterations)
     hipLaunchKernelGGL(k_prolong, G256(L.N), L.N, L.agg, L.type, L.doff, C.x, mask, gamma >= 2 ? h->over : fmin(h->over, 1.0), x);

@@ -236,6 +236,37 @@ def test_multigrid_preconditioner_same_solution_fewer_iterations():
     tiny.close()
 
 
+def test_multigrid_variants_are_the_same_preconditioner(monkeypatch):
+    """The measurement knobs of the cycle change how it is computed, not what: the small levels in one launch
+    (k_amg_tail) or kernel by kernel, the smoother's level-0 matrix in bfloat16 / float / double, a shallower hierarchy.
+    Every variant must solve the same system to the same answer; the one-launch tail repeats the kernel-by-kernel
+    iteration count exactly (same steps, same order), the matrix precision may move it by a few iterations."""
+    deck = mesh.bar_deck(dims=(8, 48, 8))
+    s, o = make_pair(deck)
+    for obj in (s, o):
+        obj.update_nodes_with_bc(1.0)
+    o.update_state(); o.create_stiffness(); o.create_residual_forces(); o.apply_prescribed_bc(0.0)
+    o.solve_slae(feahip.CHOLESKY)
+    s.close()
+    its = {}
+    for name, env in (("default", {}), ("no_tail", {"FEAHIP_AMG_TAIL": "0"}), ("f32", {"FEAHIP_AMG_FINE_BITS": "32"}),
+                      ("f64", {"FEAHIP_AMG_FINE_BITS": "64"}), ("shallow", {"FEAHIP_AMG_COARSEST": "1500", "FEAHIP_AMG_SWEEPS": "12"})):
+        for k in ("FEAHIP_AMG_TAIL", "FEAHIP_AMG_FINE_BITS", "FEAHIP_AMG_COARSEST", "FEAHIP_AMG_SWEEPS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        t = feahip.FeaSolver(deck)
+        t.update_nodes_with_bc(1.0)
+        t.create_stiffness_and_residual(); t.apply_prescribed_bc(0.0)
+        t.set_preconditioner(1)
+        its[name], res = t.solve_slae(feahip.PCG_ILU, 1e-15, 20000)
+        assert res < 1e-14, name
+        assert rel(t.solution(), o.solution()) < U_TOL, name
+        t.close()
+    assert its["default"] == its["no_tail"], its
+    assert abs(its["f32"] - its["default"]) <= 6 and abs(its["f64"] - its["default"]) <= 6, its
+
+
 @pytest.mark.parametrize("case", ["cylinder_tet10_a5", "bar_tet10_neohookean"])
 def test_multigrid_on_quadratic_elements_and_curved_geometry(case):
     """The hierarchy is built from the node graph and the node positions only:
