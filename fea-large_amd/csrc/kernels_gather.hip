@@ -68,7 +68,7 @@ void k_assemble_gather(GatherArgs A, int run_len)
   const double gauss_w = A.tab->w[0];
   // ---- prologue: maps and coordinates of the first chunk, nothing to hide behind
   GMaps mn;                                                   // "next": the chunk about to be worked on
-  g_load_maps<DOK, DOF>(A.lay, rec, t, mn);
+  g_load_maps<DOK, DOF>(A.lay, G_ABL(64) ? A.maps + (size_t)A.chunk0 * stride : rec, t, mn);      // 64: every chunk reads the first chunk's map words (timing: what de-duplicated maps could save)
   GatherHeader hn = *reinterpret_cast<const GatherHeader *>(rec);
   int node1 = reinterpret_cast<const int *>(rec + A.lay.o_nodes)[t & (FEA_G_MAX_NODES - 1)];       // node slot t of the chunk whose coordinates are loaded next
   if (node_lane) {
@@ -106,7 +106,7 @@ void k_assemble_gather(GatherArgs A, int run_len)
       // the header of the next chunk as a VECTOR load (lane l holds word l, read back with v_readlane): a scalar
       // load shares its counter with the LDS, and every barrier's wait for the LDS would wait for it as well
       hword = reinterpret_cast<const int *>(rec1)[t & 15];
-      g_load_maps<DOK, DOF>(A.lay, rec1, t, mn);
+      g_load_maps<DOK, DOF>(A.lay, G_ABL(64) ? A.maps + (size_t)A.chunk0 * stride : rec1, t, mn);
       const size_t n1 = (size_t)(node_lane ? node1 : 0);
       ca0 = *reinterpret_cast<const double2 *>(A.x + n1 * 4); ca1.x = A.x[n1 * 4 + 2];
       cc0 = *reinterpret_cast<const double2 *>(A.X0 + n1 * 4); cc1.x = A.X0[n1 * 4 + 2];
