@@ -26,7 +26,7 @@ struct GatherArgs {
   unsigned long long *stamps;    // diagnostic build only: [chunk][8] s_memtime deltas
   int ablate;                    // diagnostic build only: timing experiments (results meaningless)
 };
-#ifdef FEAHIP_DEBUG
+#if defined(FEAHIP_DEBUG) && !defined(FEAHIP_NOABL)       // FEAHIP_NOABL: stamps only, the code of the shipped kernel otherwise
 #define G_ABL(bit) (A.ablate & (bit))
 #else
 #define G_ABL(bit) 0

@@ -92,26 +92,10 @@ void k_assemble_gather(GatherArgs A, int run_len)
     const bool more = chunk + 1 < cend;
     const GatherHeader h = hn;
     int hword;
+    double2 ca0, ca1, cc0, cc1;
     const GMaps m = mn;
     const int nrows = h.r1 - h.r0;
     rec = A.maps + (size_t)(A.chunk0 + chunk) * stride;
-
-    // ---- next chunk's loads, a whole state + gather phase ahead of their first use: header, map words, node
-    // coordinates (by the node ids requested one chunk earlier), and the node ids of the chunk after it.
-    // Clamped indices instead of branches (a load under a branch is waited for at the join).
-    double2 ca0, ca1, cc0, cc1;
-    {
-      const int c1 = min(chunk + 1, cend - 1), c2 = min(chunk + 2, cend - 1);
-      const unsigned char *rec1 = A.maps + (size_t)(A.chunk0 + c1) * stride;
-      // the header of the next chunk as a VECTOR load (lane l holds word l, read back with v_readlane): a scalar
-      // load shares its counter with the LDS, and every barrier's wait for the LDS would wait for it as well
-      hword = reinterpret_cast<const int *>(rec1)[t & 15];
-      g_load_maps<DOK, DOF>(A.lay, G_ABL(64) ? A.maps + (size_t)A.chunk0 * stride : rec1, t, mn);
-      const size_t n1 = (size_t)(node_lane ? node1 : 0);
-      ca0 = *reinterpret_cast<const double2 *>(A.x + n1 * 4); ca1.x = A.x[n1 * 4 + 2];
-      cc0 = *reinterpret_cast<const double2 *>(A.X0 + n1 * 4); cc1.x = A.X0[n1 * 4 + 2];
-      node1 = reinterpret_cast<const int *>(A.maps + (size_t)(A.chunk0 + c2) * stride + A.lay.o_nodes)[t & (FEA_G_MAX_NODES - 1)];
-    }
 
     __builtin_amdgcn_s_setprio(PRIO_STATE);
     // ---- phase 1: one state evaluation per element of the chunk
@@ -149,6 +133,28 @@ void k_assemble_gather(GatherArgs A, int run_len)
 #pragma unroll
       for (int q = 0; q < REC / 2; ++q) o[q] = make_double2(0.0, 0.0);
     }
+    // ---- next chunk's loads, a gather phase ahead of their first use: header, map words, node coordinates (by the
+    // node ids requested one chunk earlier), and the node ids of the chunk after it.  Clamped indices instead of
+    // branches (a load under a branch is waited for at the join).
+    // Issued HERE, after the state evaluation: at the top of the chunk the CU's memory pipeline (one in-order queue)
+    // still holds the previous chunk's rows, 69 KB leaving at the CU's share of the HBM write rate, and a wave had to
+    // get its thirteen loads into that queue before it could start evaluating (~2 300 of the state phase's 6 900
+    // cycles, by the in-kernel stamps).  By now the rows are gone; the waves without elements issue theirs at once.
+    // (Issued BEFORE the rows instead, the loads keep the queue's entries for their whole latency and it is the row
+    // stores that cannot be issued: 8 500 cycles of write-out instead of 1 700.)
+    {
+      const int c1 = min(chunk + 1, cend - 1), c2 = min(chunk + 2, cend - 1);
+      const unsigned char *rec1 = A.maps + (size_t)(A.chunk0 + c1) * stride;
+      // the header of the next chunk as a VECTOR load (lane l holds word l, read back with v_readlane): a scalar
+      // load shares its counter with the LDS, and every barrier's wait for the LDS would wait for it as well
+      hword = reinterpret_cast<const int *>(rec1)[t & 15];
+      g_load_maps<DOK, DOF>(A.lay, G_ABL(64) ? A.maps + (size_t)A.chunk0 * stride : rec1, t, mn);
+      const size_t n1 = (size_t)(node_lane ? node1 : 0);
+      ca0 = *reinterpret_cast<const double2 *>(A.x + n1 * 4); ca1.x = A.x[n1 * 4 + 2];
+      cc0 = *reinterpret_cast<const double2 *>(A.X0 + n1 * 4); cc1.x = A.X0[n1 * 4 + 2];
+      node1 = reinterpret_cast<const int *>(A.maps + (size_t)(A.chunk0 + c2) * stride + A.lay.o_nodes)[t & (FEA_G_MAX_NODES - 1)];
+    }
+
     G_LDS_DRAIN();                                     // the asm record stores
     G_BARRIER();                                       // records visible; the coordinate tile is dead
     G_STAMP(1);
@@ -196,9 +202,6 @@ void k_assemble_gather(GatherArgs A, int run_len)
       for (int v = 2; v < h.vdepth; ++v)
         g_visit<DOK>(sT, reinterpret_cast<const unsigned short *>(rec + A.lay.o_vlist)[v * FEA_G_THREADS + t], fa);
     }
-    if (more && node_lane) {                           // next chunk's coordinates: the tile has been dead since the state phase
-      sC[t * 3] = ca0; sC[t * 3 + 1] = make_double2(ca1.x, cc0.x); sC[t * 3 + 2] = make_double2(cc0.y, cc1.x);
-    }
     G_STAMP(2);
     __builtin_amdgcn_s_setprio(PRIO_OUT);
     G_BARRIER();                                       // the records are dead: their space becomes the tile
@@ -241,6 +244,9 @@ void k_assemble_gather(GatherArgs A, int run_len)
     // for a store.
     asm volatile("" : : "v"(mn.eids), "v"(mn.tpos), "v"(mn.cw[0]), "v"(mn.cw[1]), "v"(mn.cw[2]), "v"(mn.cw[3]),
                  "v"(mn.vw[0]), "v"(mn.vw[1]), "v"(mn.kd), "v"(mn.vb), "v"(mn.ve), "v"(node1), "v"(hword));
+    if (more && node_lane) {                           // next chunk's coordinates: the tile has been dead since the state phase
+      sC[t * 3] = ca0; sC[t * 3 + 1] = make_double2(ca1.x, cc0.x); sC[t * 3 + 2] = make_double2(cc0.y, cc1.x);
+    }
     hn.r0 = __builtin_amdgcn_readlane(hword, 0); hn.r1 = __builtin_amdgcn_readlane(hword, 1);
     hn.b0 = __builtin_amdgcn_readlane(hword, 2); hn.nb = __builtin_amdgcn_readlane(hword, 3);
     hn.nnode = __builtin_amdgcn_readlane(hword, 4); hn.nelem = __builtin_amdgcn_readlane(hword, 5);
@@ -300,7 +306,7 @@ void k_assemble_gather(GatherArgs A, int run_len)
   }
 #ifdef FEAHIP_DEBUG
   if (A.stamps && (t & 63) == 0) {                     // one line per wave: [run][wave][8]
-    unsigned long long *o = A.stamps + ((size_t)ridx * 4 + (t >> 6)) * 8;
+    unsigned long long *o = A.stamps + ((size_t)ridx * (FEA_G_THREADS / 64) + (t >> 6)) * 8;
     for (int i = 0; i < 6; ++i) o[i] = sa[i];
     o[6] = __builtin_amdgcn_s_memtime() - clk0;          // shader cycles of this run ...
     o[7] = __builtin_amdgcn_s_memrealtime() - real0;     // ... and 100 MHz ticks: their ratio is the in-kernel clock
@@ -360,8 +366,8 @@ int launch_assemble_gather(feahip_ctx *c, bool doK, bool doF)
   if (dbg && atoi(dbg)) {
     if (!d_stamps || stamps_cap < c->ngchunks) {
       if (d_stamps) (void)hipFree(d_stamps);
-      (void)hipMalloc((void **)&d_stamps, sizeof(unsigned long long) * 32 * (size_t)c->ngchunks);
-      (void)hipMemset(d_stamps, 0, sizeof(unsigned long long) * 32 * (size_t)c->ngchunks);
+      (void)hipMalloc((void **)&d_stamps, sizeof(unsigned long long) * 8 * (FEA_G_THREADS / 64) * (size_t)c->ngchunks);
+      (void)hipMemset(d_stamps, 0, sizeof(unsigned long long) * 8 * (FEA_G_THREADS / 64) * (size_t)c->ngchunks);
       stamps_cap = c->ngchunks;
     }
     A.stamps = d_stamps;
@@ -398,15 +404,16 @@ int launch_assemble_gather(feahip_ctx *c, bool doK, bool doF)
     static int calls = 0;
     if (++calls == 50) {
       (void)hipStreamSynchronize(c->stream);
-      std::vector<unsigned long long> hst((size_t)c->ngchunks * 32);
+      constexpr int NW = FEA_G_THREADS / 64;
+      std::vector<unsigned long long> hst((size_t)c->ngchunks * 8 * NW);
       (void)hipMemcpy(hst.data(), A.stamps, hst.size() * 8, hipMemcpyDeviceToHost);
-      double sum[4][8] = {};
+      double sum[NW][8] = {};
       for (int i = 0; i < nruns; ++i)
-        for (int w = 0; w < 4; ++w)
-          for (int q = 0; q < 8; ++q) sum[w][q] += (double)hst[((size_t)i * 4 + w) * 8 + q];
+        for (int w = 0; w < NW; ++w)
+          for (int q = 0; q < 8; ++q) sum[w][q] += (double)hst[((size_t)i * NW + w) * 8 + q];
       fprintf(stderr, "[gather stamps] in-kernel clock %.0f MHz (s_memtime / s_memrealtime x 100 MHz over a run), run = %.0f shader cycles for %d chunks\n",
               sum[0][7] > 0 ? 100.0 * sum[0][6] / sum[0][7] : 0.0, sum[0][6] / nruns, run_len);
-      for (int w = 0; w < 4; ++w)
+      for (int w = 0; w < NW; w += (NW > 4 ? 5 : 1))
         fprintf(stderr, "[gather stamps K=%d F=%d wave %d, per chunk] state %.0f  prefetch+gather %.0f  barrier %.0f  tile %.0f  diag+drain %.0f  writeout %.0f cycles\n",
                 (int)doK, (int)doF, w, sum[w][0] / c->ngchunks, sum[w][1] / c->ngchunks, sum[w][2] / c->ngchunks, sum[w][3] / c->ngchunks,
                 sum[w][4] / c->ngchunks, sum[w][5] / c->ngchunks);
