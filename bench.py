@@ -150,6 +150,7 @@ def main():
                     "--quadratic), or bx,by,bz")
     ap.add_argument("--cpu-single-only", action="store_true", help="skip the one-oracle-copy-per-core CPU baseline")
     ap.add_argument("--no-tet10", action="store_true", help="skip the small TET10 leg of extras")
+    ap.add_argument("--pcg-variant", type=int, default=-1, help="-1: the context's default; 0: two-reduction PCG; 1: single-reduction PCG")
     args = ap.parse_args()
     if args.cpu_sample is None:
         args.cpu_sample = 0 if args.hex else 14 if args.quadratic else 48     # (the CPU legs are wired for the tet blocks)
@@ -212,6 +213,8 @@ def main():
         solver = feahip.FeaSolver(deck, device=local)
         local_nodes = slice(None)
     solver.set_assembly(getattr(feahip, "ASM_" + args.assembly.upper()))
+    if args.pcg_variant >= 0:
+        solver.set_pcg_variant(args.pcg_variant)
     solver.set_nodes(mesh.deformed_state(deck.nodes)[local_nodes])
     solver.create_stiffness_and_residual()              # builds the assembly maps of the rows this rank owns
     solver.sync()
