@@ -331,6 +331,25 @@ __device__ __forceinline__ double lintet_record_a5(const double (&x)[4][3], cons
   return detJ;
 }
 
+// v + (v of the lane whose id differs in bit 0), then the same over bit 1: the sum of a quad, in every lane of it, by
+// DPP quad permutes (VALU only).  __shfl_xor compiles to ds_bpermute_b32, an LDS-pipe instruction per 32-bit half and
+// step: the 72 of them a diagonal wave issued for its nine sums queued behind the block waves' tile writes and made
+// the four diagonal waves the last to finish the tile phase (2 600 of its 2 950 cycles, by the in-kernel stamps).
+template <int CTRL>
+__device__ __forceinline__ double g_quad_perm(double x)
+{
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double g_quad_sum(double v)
+{
+  v += g_quad_perm<0xB1>(v);            // quad_perm [1,0,3,2]
+  v += g_quad_perm<0x4E>(v);            // quad_perm [2,3,0,1]
+  return v;
+}
+
 // workgroup barrier that orders LDS only: __syncthreads() would also drain every global load and store in flight
 // (s_waitcnt vmcnt(0)), i.e. the prefetches of the next chunk and the row stores of the previous one
 #define G_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); \

@@ -225,10 +225,10 @@ void k_assemble_gather(GatherArgs A, int run_len)
     }
     if (DOK && t >= G_TASK_THREADS) {                  // the four partial sums of a row's diagonal block meet in its first lane
 #pragma unroll
-      for (int q = 0; q < 6; ++q) { dg[q] += __shfl_xor(dg[q], 1); dg[q] += __shfl_xor(dg[q], 2); }
+      for (int q = 0; q < 6; ++q) dg[q] = g_quad_sum(dg[q]);
       if (DOF) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { fa[q] += __shfl_xor(fa[q], 1); fa[q] += __shfl_xor(fa[q], 2); }
+        for (int q = 0; q < 3; ++q) fa[q] = g_quad_sum(fa[q]);
       }
       if ((t & 3) == 0 && t - G_TASK_THREADS < 4 * nrows) {
         double *o = sK + m.kd * 9;
