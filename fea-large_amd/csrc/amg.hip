@@ -1,5 +1,6 @@
 // amg.hip -- device side of the aggregation multigrid preconditioner (amg.h).
 #include "amg.h"
+#include "dpp_device.h"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -95,10 +96,7 @@ void k_galerkin(int npair, const int *prow, const int *crowptr, const int *cbptr
   for (int w = 0; w < 4; ++w)
 #pragma unroll
     for (int e = 0; e < 9; ++e) {
-      double v = acc[w][e];
-#pragma unroll
-      for (int o = FEA_GAL_LANES / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, FEA_GAL_LANES);
-      acc[w][e] = v;
+      acc[w][e] = dpp_row16_sum(acc[w][e]);
     }
   if (!on || sub >= 4) return;
   const int I = prow[kp];
@@ -185,9 +183,7 @@ void k_restrict(int nagg, const int *aptr, const int *anodes, const uint8_t *typ
     }
   }
 #pragma unroll
-  for (int w = 8; w > 0; w >>= 1)
-#pragma unroll
-    for (int q = 0; q < 6; ++q) s[q] += __shfl_xor(s[q], w, 16);
+  for (int q = 0; q < 6; ++q) s[q] = dpp_row16_sum(s[q]);
   if (A < nagg && sub < 6) rc[(size_t)A * 6 + sub] = s[sub];
 }
 
@@ -396,8 +392,7 @@ __device__ __forceinline__ void t_spmv(const TailLevel &L, double *smem)
         }
       }
     }
-    a0 += __shfl_xor(a0, 1); a1 += __shfl_xor(a1, 1); a2 += __shfl_xor(a2, 1);
-    a0 += __shfl_xor(a0, 2); a1 += __shfl_xor(a1, 2); a2 += __shfl_xor(a2, 2);
+    a0 = dpp_quad_sum(a0); a1 = dpp_quad_sum(a1); a2 = dpp_quad_sum(a2);
     if (row < L.N && sub < 3) y[row * 3 + sub] = sub == 0 ? a0 : (sub == 1 ? a1 : a2);
   }
 }
@@ -425,9 +420,7 @@ __device__ __forceinline__ void t_restrict(const TailLevel &L, const TailLevel &
       }
     }
 #pragma unroll
-    for (int w = 8; w > 0; w >>= 1)
-#pragma unroll
-      for (int q = 0; q < 6; ++q) s[q] += __shfl_xor(s[q], w, 16);
+    for (int q = 0; q < 6; ++q) s[q] = dpp_row16_sum(s[q]);
     if (A < L.nagg && sub < 6) rc[A * 6 + sub] = s[sub];
   }
 }
