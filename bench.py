@@ -7,7 +7,8 @@ one-time pattern build excluded), inputs resident in HBM.  Default workload:
 BASELINE.json configs[2], the 10M linear-tet Neo-Hookean block
 (66 x 396 x 66 Kuhn cubes on the reference's 1 x 6 x 1 bar).
 
-  python bench.py --gpus N --steps K --warmup W          (N = 1)
+  python bench.py --gpus N --steps K --warmup W          (any N: with N > 1 and no WORLD_SIZE in the environment
+                                                          this process starts the N ranks itself, as children)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 With N > 1 the block rows (hence the elements that touch them) are sharded
@@ -65,7 +66,8 @@ def kernel_code_hash():
     carries the hash its PMC passes were measured at."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels_gather.hip", "gather_device.h", "gather.cpp", "fem_device.h", "renumber.cpp"):
+    for f in ("kernels_gather.hip", "gather_device.h", "gather.cpp", "fem_device.h", "renumber.cpp", "feahip_internal.h", "pattern.cpp",
+              "kernels_assemble.hip", "dpp_device.h"):
         with open(os.path.join(ROOT, "fea-large_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -132,6 +134,48 @@ def cpu_baseline_all_cores(n_sample, quadratic, model, cores):
             "slowest_copy_s": max(r["dt"] for r in outs), "elements_per_copy": E}
 
 
+def self_launch(n, argv):
+    """`python3 bench.py --gpus N` started by hand (no torch.distributed.run around it): this process touches neither
+    the GPU nor torch; it starts the N ranks as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
+    torch.distributed.run would set them), lets rank 0's stdout through (the ONE JSON line), and leaves with the
+    worst return code.  One command drives all ranks, as one solve() call does in the reference (fea_solver.c:130-242).
+    Never os.exec*: a process that replaces itself after the GPU was initialised takes the box down."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FEAHIP_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    # a rank that dies leaves the others in a barrier: once one has failed the rest get a grace period, then SIGTERM
+    # by PID (never by pattern); the whole launch is bounded as well
+    deadline = time.time() + float(os.environ.get("FEAHIP_BENCH_LAUNCH_TIMEOUT", "1500"))
+    failed_at = None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+            failed_at = time.time()
+        if (failed_at is not None and time.time() - failed_at > 60) or time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            time.sleep(5)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+    rcs = [p.wait() for p in procs]
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print("bench.py: ranks with a non-zero exit code: " + ", ".join(f"rank {r}: {rc}" for r, rc in bad), file=sys.stderr)
+    return next((min(abs(rc), 255) for rc in rcs if rc != 0), 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,6 +199,9 @@ def main():
     if args.cpu_sample is None:
         args.cpu_sample = 0 if args.hex else 14 if args.quadratic else 48     # (the CPU legs are wired for the tet blocks)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started like `--gpus 1` is started: become the launcher (before feahip / torch / any GPU call)
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -287,9 +334,10 @@ def main():
             verified = ok
         except Exception as e:                      # noqa: BLE001
             verified = f"check failed to run: {e}"
-    copy_gbps = None
+    copy_gbps = copy3 = None
     try:
-        copy_gbps = solver.copy_bandwidth(1 << 30)
+        copy3 = solver.copy_bandwidth_detail(1 << 30)
+        copy_gbps = max(copy3)
     except Exception as e:                          # noqa: BLE001
         print(f"copy bandwidth not measured: {e}", file=sys.stderr)
     B = algorithmic_bytes(sz["npe"], E_total, N, nnz) * share
@@ -308,6 +356,8 @@ def main():
                            "; library: " + ("renumbered to compact cells (csrc/renumber.cpp)" if renumbered else "the caller's ids kept")),
         "verified": verified,
         "copy_bandwidth_GBps": copy_gbps,
+        "copy_bandwidth_GBps_by_method": (dict(zip(("one_16B_load_per_lane", "four_16B_loads_in_flight", "hipMemcpyDtoDAsync", "four_16B_nontemporal"), copy3))
+                                          if copy3 else None),
         "assembly_frac_of_copy_bandwidth": achieved / copy_gbps if copy_gbps else None,
         "device_addresses_mod_2MiB": {k: v % (1 << 21) for k, v in solver.device_layout().items()},
         "rank0_holds": ({"nodes": solver.N, "owned_nodes": solver.n_own, "elements": solver.E, "rows_sent_per_exchange": solver.rows_sent}

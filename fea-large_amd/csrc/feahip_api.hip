@@ -882,8 +882,14 @@ extern "C" int feahip_time_kernel(feahip_ctx *c, int what, int warmup, int iters
   return FEAHIP_OK;
 }
 
-// plain streaming copy, 16 bytes per lane: the copy bandwidth of THIS box, the figure the roofline fractions can be
-// quoted against next to the 8 TB/s of the data sheet (MI355X_MICROARCH.md measures 6.29 TB/s this way)
+// Streaming copies: the copy bandwidth of THIS box, the figure the roofline fractions can be quoted against next to the
+// 8 TB/s of the data sheet (MI355X_MICROARCH.md measures 6.29 TB/s with a float4 copy).  Four ways, the
+// best one is reported (feahip_copy_bandwidth) and all four are available (feahip_copy_bandwidth_detail):
+//   [0] one 16-byte load in flight per lane, grid-stride (rounds 1-3);
+//   [1] FOUR independent 16-byte loads in flight per lane, then their four stores -- each workgroup streams a
+//       contiguous 16 KB tile per step, 16 workgroups per CU;
+//   [2] hipMemcpyDtoDAsync (the runtime's blit kernel);
+//   [3] as [1] with non-temporal loads and stores.
 __global__ __launch_bounds__(256)
 void k_copy16(const double2 *__restrict__ src, double2 *__restrict__ dst, size_t n)
 {
@@ -891,30 +897,70 @@ void k_copy16(const double2 *__restrict__ src, double2 *__restrict__ dst, size_t
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
-extern "C" int feahip_copy_bandwidth(feahip_ctx *c, long long bytes, double *gbytes_per_s)
+typedef double copy_v2d __attribute__((ext_vector_type(2)));
+template <bool NT>
+__global__ __launch_bounds__(256)
+void k_copy16x4(const copy_v2d *__restrict__ src, copy_v2d *__restrict__ dst, size_t n)
+{
+  // tile = 4 x 256 pieces of 16 bytes; tiles dealt round-robin to the workgroups
+  const size_t ntiles = n >> 10;
+  for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const size_t i = (tile << 10) + threadIdx.x;
+    copy_v2d a, b, c, d;
+    if (NT) { a = __builtin_nontemporal_load(src + i); b = __builtin_nontemporal_load(src + i + 256);
+              c = __builtin_nontemporal_load(src + i + 512); d = __builtin_nontemporal_load(src + i + 768); }
+    else { a = src[i]; b = src[i + 256]; c = src[i + 512]; d = src[i + 768]; }
+    if (NT) { __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + 256);
+              __builtin_nontemporal_store(c, dst + i + 512); __builtin_nontemporal_store(d, dst + i + 768); }
+    else { dst[i] = a; dst[i + 256] = b; dst[i + 512] = c; dst[i + 768] = d; }
+  }
+  for (size_t i = (ntiles << 10) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+extern "C" int feahip_copy_bandwidth_detail(feahip_ctx *c, long long bytes, double *gbytes_per_s4)
 {
   CTX_GUARD_NOK(c);
-  if (!gbytes_per_s || bytes < (1 << 20)) return FEAHIP_EINVAL;
+  if (!gbytes_per_s4 || bytes < (1 << 20)) return FEAHIP_EINVAL;
   const size_t n = (size_t)bytes / 16;
   double2 *a = nullptr, *b = nullptr;
   FEA_HIP_CHECK(c, hipMalloc((void **)&a, n * 16));
   if (hipMalloc((void **)&b, n * 16) != hipSuccess) { (void)hipFree(a); c->err = "out of device memory"; return FEAHIP_ENOMEM; }
   (void)hipMemsetAsync(a, 0x3c, n * 16, c->stream);
   const int grid = 256 * 16;
-  for (int k = 0; k < 3; ++k) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, c->stream, a, b, n);
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  (void)hipEventRecord(e0, c->stream);
+  hipError_t err = hipSuccess;
   const int reps = 10;
-  for (int k = 0; k < reps; ++k) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, c->stream, a, b, n);
-  (void)hipEventRecord(e1, c->stream);
-  const hipError_t err = hipEventSynchronize(e1);
-  float ms = 0;
-  (void)hipEventElapsedTime(&ms, e0, e1);
+  for (int m = 0; m < 4; ++m) {
+    auto one = [&]() {
+      if (m == 0) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, c->stream, a, b, n);
+      else if (m == 1) hipLaunchKernelGGL(k_copy16x4<false>, dim3(grid), dim3(256), 0, c->stream, (const copy_v2d *)a, (copy_v2d *)b, n);
+      else if (m == 3) hipLaunchKernelGGL(k_copy16x4<true>, dim3(grid), dim3(256), 0, c->stream, (const copy_v2d *)a, (copy_v2d *)b, n);
+      else (void)hipMemcpyDtoDAsync((hipDeviceptr_t)b, (hipDeviceptr_t)a, n * 16, c->stream);
+    };
+    for (int k = 0; k < 3; ++k) one();
+    (void)hipEventRecord(e0, c->stream);
+    for (int k = 0; k < reps; ++k) one();
+    (void)hipEventRecord(e1, c->stream);
+    const hipError_t e = hipEventSynchronize(e1);
+    if (e != hipSuccess) err = e;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    gbytes_per_s4[m] = ms > 0 ? 2.0 * (double)(n * 16) * reps / ((double)ms * 1e-3) / 1e9 : 0.0;      // read + written
+  }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(a); (void)hipFree(b);
-  if (err != hipSuccess || !(ms > 0)) { c->err = "copy kernel failed"; return FEAHIP_EHIP; }
-  *gbytes_per_s = 2.0 * (double)(n * 16) * reps / ((double)ms * 1e-3) / 1e9;      // read + written
+  if (err != hipSuccess || !(gbytes_per_s4[0] > 0)) { c->err = "copy kernel failed"; return FEAHIP_EHIP; }
+  return FEAHIP_OK;
+}
+
+extern "C" int feahip_copy_bandwidth(feahip_ctx *c, long long bytes, double *gbytes_per_s)
+{
+  double v[4] = {0, 0, 0, 0};
+  if (!gbytes_per_s) return FEAHIP_EINVAL;
+  const int rc = feahip_copy_bandwidth_detail(c, bytes, v);
+  if (rc) return rc;
+  *gbytes_per_s = std::max(std::max(v[0], v[1]), std::max(v[2], v[3]));
   return FEAHIP_OK;
 }
 

@@ -277,8 +277,11 @@ struct GatherHeader {                // 64 bytes, first thing in a chunk record
   int nnode, nelem, noffd, depth;    // depth: contribution words per block thread
   int nvthr, vdepth;                 // residual threads, visits per residual thread
   int ddepth;                        // diagonal-block words per lane of the last wave
-  int pad[5];
+  unsigned wdepth[3];                // contribution words the block threads of wave slot w walk (the longest list of ITS blocks), one byte per slot
+  int flags;                         // bit 0: the map words of the NEXT chunk of the context (everything but header and node list) equal this chunk's
+  int pad[1];
 };
+static_assert(sizeof(GatherHeader) == 64 && FEA_G_TASK_THREADS / 64 <= 12, "GatherHeader: 64 bytes, twelve block-wave slots");
 struct GatherLayout {                // the same for every chunk of a context
   int stride;                        // bytes per chunk record
   int o_nodes, o_elems, o_bpos, o_rows, o_vlist, o_dlist, o_clist;   // byte offsets of the sections
@@ -291,6 +294,7 @@ struct HostGather {
   std::vector<int> first_row;        // [nchunks+1]
   long long total_evals = 0, distinct_elems = 0;   // element evaluations of all chunks; elements touching the rows
   int nchunks = 0;
+  int same_as_previous = 0;          // chunks whose map words equal their predecessor's (GatherHeader::flags)
   bool ok = false;
 };
 // rows [row_lo, row_hi) only: a rank builds the maps of the rows it owns

@@ -181,10 +181,11 @@ void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int
       if (nnslots > FEA_G_MAX_NODES || nslots > FEA_G_MAX_SLOTS || nrows > FEA_G_MAX_ROWS) { bad[p] = 1; continue; }
       auto lnode = [&](int g) { return (int)(std::lower_bound(nd.begin(), nd.end(), g) - nd.begin()); };
       auto lelem = [&](int e) { return (int)(std::lower_bound(el.begin(), el.end(), e) - el.begin()); };
-      // block threads: the off-diagonal blocks in CSR order; a block whose column is a LOWER row of the same chunk
-      // has no thread of its own, it is the transpose of its mirror block
+      // blocks with a thread: the off-diagonal blocks in CSR order; a block whose column is a LOWER row of the same chunk
+      // has no thread of its own, it is the transpose of its mirror block.  blk_of[pos] = index of the block at tile
+      // position pos; which THREAD serves it is decided below, once the lists are known.
       tid_of.assign((size_t)nb, -1);
-      L.tpos.clear();
+      std::vector<uint32_t> btpos;
       L.rows.assign(G_ROWS_U16, 0);
       for (int a = r0; a < r1; ++a) {
         L.rows[G_RS + (a - r0)] = (uint16_t)(hp.rowptr[a] - b0);
@@ -198,16 +199,16 @@ void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int
             const int m = hp.rowptr[b] + (int)(std::lower_bound(cb, ce, a) - cb) - b0;
             w = (uint32_t)(q - b0) | ((uint32_t)m << 16);
           }
-          tid_of[q - b0] = (int)L.tpos.size();
-          L.tpos.push_back(w);
+          tid_of[q - b0] = (int)btpos.size();
+          btpos.push_back(w);
         }
       }
       L.rows[G_RS + nrows] = (uint16_t)nb;
-      const int ntask = (int)L.tpos.size();
-      if (ntask > G_TASK_THREADS) { bad[p] = 1; continue; }
-      // contributions per block thread, and per row the visits of its diagonal block (four lanes of the last wave
+      const int nblk = (int)btpos.size();
+      if (nblk > G_TASK_THREADS) { bad[p] = 1; continue; }
+      // contributions per block, and per row the visits of its diagonal block (four lanes of the last waves
       // per row: a row's diagonal block is summed from the records like any other block, K_aa = sum_e K_aa^e)
-      lists.assign((size_t)ntask, std::vector<uint16_t>());
+      std::vector<std::vector<uint16_t>> blists((size_t)nblk);
       dl.assign((size_t)4 * FEA_G_MAX_ROWS, std::vector<uint16_t>());
       for (int a = r0; a < r1; ++a) {
         const int *cb = hp.colidx.data() + hp.rowptr[a], *ce = hp.colidx.data() + hp.rowptr[a + 1];
@@ -222,10 +223,87 @@ void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int
             if (b == a) continue;                 // degenerate element (repeated node): no off-diagonal block
             const int pos = hp.rowptr[a] + (int)(std::lower_bound(cb, ce, b) - cb) - b0;
             if (tid_of[pos] < 0) continue;        // served by the mirror block's thread
-            lists[(size_t)tid_of[pos]].push_back((uint16_t)(le | (la << 10) | (lb << 12)));
+            blists[(size_t)tid_of[pos]].push_back((uint16_t)(le | (la << 10) | (lb << 12)));
           }
         }
       }
+      // ---- which thread serves which block.  A wave walks its lists to the depth of its LONGEST one (empty entries
+      // read the all-zero record), and the gather phase lasts as long as its busiest SIMD: in CSR order every wave
+      // of a Kuhn block mixes blocks of 4 and of 6 contributions and walks 6, and ten block waves over four SIMDs
+      // are 3 + 3 + 2 + 2.  So (i) the blocks are sorted by list length, a wave holds lists of (nearly) one length and
+      // stops at its own depth (GatherHeader::wdepth); (ii) the waves are dealt to the wave slots so that the four
+      // SIMDs carry equal sums of depths -- a workgroup's waves go to the SIMDs cyclically, slot w runs on SIMD
+      // (w + start) mod 4, and the slots s, s+4, s+8 of the block waves share one (longest wave first, to the
+      // lightest SIMD with a free slot); (iii) inside a wave sixteen consecutive lanes (one group of the tile
+      // phase's ds_write_b64) get tile positions that differ mod 16, mirrors too where possible: a block is nine
+      // doubles, so two blocks meet in a bank exactly when their positions agree mod 16.
+      std::vector<int> thr_blk((size_t)G_TASK_THREADS, -1);      // thread -> block
+      int wdepth[G_TASK_THREADS / 64] = {0};
+      int ntask = 0;
+      {
+        constexpr int NBW = G_TASK_THREADS / 64;
+        auto words = [&](int i) { return ((int)blists[i].size() + 1) / 2; };
+        std::vector<int> ord((size_t)nblk);
+        for (int i = 0; i < nblk; ++i) ord[i] = i;
+        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return words(x) > words(y); });
+        // sixteens with distinct tile positions mod 16, class by class (a class = one list length in words)
+        std::vector<int> seq;
+        seq.reserve((size_t)nblk);
+        for (size_t c0 = 0; c0 < ord.size();) {
+          size_t c1 = c0;
+          while (c1 < ord.size() && words(ord[c1]) == words(ord[c0])) ++c1;
+          std::vector<int> bucket[16];
+          for (size_t k = c0; k < c1; ++k) bucket[btpos[ord[k]] & 15u].push_back(ord[k]);
+          size_t left = c1 - c0;
+          while (left) {
+            // finish the sixteen the previous class may have left open, then whole sixteens
+            const int room = 16 - (int)(seq.size() & 15);
+            int rs[16];
+            for (int r = 0; r < 16; ++r) rs[r] = r;
+            std::stable_sort(rs, rs + 16, [&](int x, int y) { return bucket[x].size() > bucket[y].size(); });
+            unsigned mused = 0;
+            int taken = 0;
+            for (int pass = 0; pass < 2 && taken < room && left; ++pass)      // pass 1: a second block of a residue, if the sixteen would stay short
+              for (int q = 0; q < 16 && taken < room && left; ++q) {
+                std::vector<int> &bk = bucket[rs[q]];
+                if (bk.empty()) continue;
+                size_t pick = 0;                                              // prefer a mirror position not yet in the sixteen
+                for (size_t c = 0; c < bk.size() && c < 8; ++c) {
+                  const unsigned mp = btpos[bk[c]] >> 16;
+                  if (mp == 0xFFFFu || !((mused >> (mp & 15u)) & 1u)) { pick = c; break; }
+                }
+                const unsigned mp = btpos[bk[pick]] >> 16;
+                if (mp != 0xFFFFu) mused |= 1u << (mp & 15u);
+                seq.push_back(bk[pick]);
+                bk.erase(bk.begin() + (long)pick);
+                ++taken; --left;
+              }
+          }
+          c0 = c1;
+        }
+        const int nwaves = (nblk + 63) / 64;
+        std::vector<int> wcost((size_t)nwaves, 0), word((size_t)nwaves);
+        for (int w = 0; w < nwaves; ++w) {
+          for (int l = 0; l < 64 && w * 64 + l < nblk; ++l) wcost[w] = std::max(wcost[w], words(seq[(size_t)w * 64 + l]));
+          word[w] = w;
+        }
+        std::stable_sort(word.begin(), word.end(), [&](int x, int y) { return wcost[x] > wcost[y]; });
+        int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0};
+        for (int w : word) {
+          int bs = -1;
+          for (int sd = 0; sd < 4; ++sd)
+            if (used[sd] * 4 + sd < NBW && (bs < 0 || load[sd] < load[bs])) bs = sd;
+          const int slot = used[bs] * 4 + bs;
+          ++used[bs]; load[bs] += wcost[w];
+          wdepth[slot] = wcost[w];
+          for (int l = 0; l < 64 && w * 64 + l < nblk; ++l) thr_blk[(size_t)slot * 64 + l] = seq[(size_t)w * 64 + l];
+          ntask = std::max(ntask, slot * 64 + std::min(64, nblk - w * 64));
+        }
+      }
+      L.tpos.assign((size_t)ntask, 0xFFFFFFFFu);                  // a thread without a block: no tile position, empty lists
+      lists.assign((size_t)ntask, std::vector<uint16_t>());
+      for (int t = 0; t < ntask; ++t)
+        if (thr_blk[t] >= 0) { L.tpos[t] = btpos[thr_blk[t]]; lists[t] = blists[thr_blk[t]]; }
       int depth = 0, ddepth = 0;
       for (auto &l : lists) depth = std::max(depth, (int)l.size());
       for (auto &l : dl) ddepth = std::max(ddepth, (int)l.size());
@@ -367,6 +445,7 @@ void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int
       memset(&h, 0, sizeof(h));
       h.r0 = r0; h.r1 = r1; h.b0 = b0; h.nb = nb; h.nnode = nnslots; h.nelem = nslots; h.noffd = ntask;
       h.depth = dwords; h.nvthr = nvthr; h.vdepth = vdepth; h.ddepth = ddwords;
+      for (int w = 0; w < G_TASK_THREADS / 64; ++w) h.wdepth[w >> 2] |= (unsigned)std::min(wdepth[w], 255) << (8 * (w & 3));
     }
   });
   for (int p = 0; p < nch; ++p)
@@ -408,6 +487,17 @@ void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int
       memcpy(rec + lay.o_clist, L.clist.data(), L.clist.size() * 2);
     }
   });
+  // a chunk whose successor has the same map words (chunk-local indices only: the interior bricks of a structured
+  // block are all alike) says so in its header: the kernel then keeps the words in registers instead of loading them
+  out.same_as_previous = 0;
+  for (int p = 0; p + 1 < nch; ++p) {
+    const unsigned char *r0 = out.blob.data() + (size_t)p * lay.stride, *r1 = r0 + lay.stride;
+    const GatherHeader &h0 = *reinterpret_cast<const GatherHeader *>(r0), &h1 = *reinterpret_cast<const GatherHeader *>(r1);
+    const bool same = h0.nelem == h1.nelem && h0.noffd == h1.noffd && h0.depth == h1.depth && h0.nvthr == h1.nvthr &&
+                      h0.vdepth == h1.vdepth && h0.ddepth == h1.ddepth && h0.r1 - h0.r0 == h1.r1 - h1.r0 &&
+                      memcmp(r0 + lay.o_elems, r1 + lay.o_elems, (size_t)(lay.stride - lay.o_elems)) == 0;
+    if (same) { reinterpret_cast<GatherHeader *>(out.blob.data() + (size_t)p * lay.stride)->flags |= 1; ++out.same_as_previous; }
+  }
   out.nchunks = nch;
   out.total_evals = 0;
   for (const Local &L : loc) {
@@ -474,6 +564,7 @@ void gather_row_digest(const HostGather &hg, const HostPattern &hp, unsigned lon
       return a;
     };
     for (int t = 0; t < h.noffd; ++t) {
+      if (tpos[t] == 0xFFFFFFFFu) continue;             // a thread without a block
       const int bpos = (int)(tpos[t] & 0xFFFFu), mpos = (int)(tpos[t] >> 16);
       const int a = row_of(bpos), b = hp.colidx[h.b0 + bpos];
       for (int k = 0; k < 2 * h.depth; ++k) {

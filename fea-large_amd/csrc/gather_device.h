@@ -64,7 +64,9 @@ __device__ __forceinline__ GRead g_fetch(const double *sT, unsigned w)
   r.pa = T[la]; r.za = T[8 + la]; r.pb = T[lb]; r.qb = T[4 + lb]; r.zb = T[8 + lb]; r.vv = T[12];
   return r;
 }
-__device__ __forceinline__ void g_apply(const GRead &r, double (&acc)[9])
+// acc[0..8]: the block without the isotropic term; accd: the isotropic term sum_e g_a . t_b, kept apart (one fused chain,
+// no additions onto the three diagonal entries per contribution) and added to them once, by g_finish
+__device__ __forceinline__ void g_apply(const GRead &r, double (&acc)[9], double &accd)
 {
   const double ga0 = r.pa.x, ga1 = r.pa.y, ga2 = r.za.x;
   const double gb0 = r.pb.x, gb1 = r.pb.y, gb2 = r.zb.x;
@@ -72,15 +74,18 @@ __device__ __forceinline__ void g_apply(const GRead &r, double (&acc)[9])
   const double vl = r.vv.x, vm = r.vv.y;
   const double h0 = vl * gb0, h1 = vl * gb1, h2 = vl * gb2;
   const double m0 = vm * gb0, m1 = vm * gb1, m2 = vm * gb2;
-  const double d = ga0 * tb0 + ga1 * tb1 + ga2 * tb2;
-  acc[0] += d; acc[4] += d; acc[8] += d;
+  accd = fma(ga0, tb0, fma(ga1, tb1, fma(ga2, tb2, accd)));
   acc[0] = fma(ga0, h0, fma(ga0, m0, acc[0])); acc[1] = fma(ga0, h1, fma(ga1, m0, acc[1])); acc[2] = fma(ga0, h2, fma(ga2, m0, acc[2]));
   acc[3] = fma(ga1, h0, fma(ga0, m1, acc[3])); acc[4] = fma(ga1, h1, fma(ga1, m1, acc[4])); acc[5] = fma(ga1, h2, fma(ga2, m1, acc[5]));
   acc[6] = fma(ga2, h0, fma(ga0, m2, acc[6])); acc[7] = fma(ga2, h1, fma(ga1, m2, acc[7])); acc[8] = fma(ga2, h2, fma(ga2, m2, acc[8]));
 }
-__device__ __forceinline__ void g_consume(const double *sT, unsigned w, double (&acc)[9])
+__device__ __forceinline__ void g_finish(double (&acc)[9], double accd)
 {
-  g_apply(g_fetch(sT, w), acc);
+  acc[0] += accd; acc[4] += accd; acc[8] += accd;
+}
+__device__ __forceinline__ void g_consume(const double *sT, unsigned w, double (&acc)[9], double &accd)
+{
+  g_apply(g_fetch(sT, w), acc, accd);
 }
 __device__ __forceinline__ void g_apply_cheap(const GRead &r, double (&acc)[9])
 {
@@ -113,20 +118,6 @@ __device__ __forceinline__ void g_consume_diag(const double *sT, unsigned w, dou
   }
 }
 
-// The same sums with the LDS reads of ALL the listed contributions issued before the first is summed: a wave that
-// reads one contribution, waits, and sums it pays the LDS latency once per contribution (measured in the producer /
-// consumer kernel, two waves per SIMD: 350-600 cycles per contribution); issued together the reads queue in the LDS
-// pipe and return while the earlier ones are summed.  D = list words (two contributions each) held in registers.
-template <int K0, int D>
-__device__ __forceinline__ void g_gather_batch(const double *sT, const unsigned (&cw)[FEA_G_REGW], double (&acc)[9])
-{
-  GRead r[2 * D];
-#pragma unroll
-  for (int k = 0; k < D; ++k) { r[2 * k] = g_fetch(sT, cw[K0 + k] & 0xFFFFu); r[2 * k + 1] = g_fetch(sT, cw[K0 + k] >> 16); }
-#pragma unroll
-  for (int k = 0; k < 2 * D; ++k) g_apply(r[k], acc);
-}
-
 // residual contribution of one (element, local node) visit: -vol sigma g_a (fea_solver.c:1096-1109)
 template <bool DOK>
 __device__ __forceinline__ void g_visit(const double *sT, unsigned w, double (&fa)[3])
@@ -151,6 +142,17 @@ __device__ __forceinline__ void g_visit(const double *sT, unsigned w, double (&f
 // them itself (G_LDS_DRAIN) before the barrier.
 #define G_W2(addr, a, b, o) asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(addr), "v"(a), "v"(b), "n"(o), "n"((o) + 1) : "memory")
 #define G_LDS_DRAIN() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#ifndef G_W128
+#define G_W128 1
+#endif
+typedef double g_v2d __attribute__((ext_vector_type(2)));
+#if G_W128
+// one piece = one ds_write_b128: eight consecutive lanes cover the 32 write banks once at the 208-byte record stride
+// (conflict-free, where the two halves of ds_write2_b64 at a 16-byte-aligned stride meet two ways); the pair has to sit
+// in four consecutive registers, which is the register allocator's business here
+#undef G_W2
+#define G_W2(addr, a, b, o) do { const g_v2d pr_ = {a, b}; asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(addr), "v"(pr_), "n"((o) * 8) : "memory"); } while (0)
+#endif
 
 template <bool DOK>
 __device__ __forceinline__ void g_store_record(double *dst, const double *R)
@@ -218,28 +220,32 @@ __device__ __forceinline__ double lintet_record_nh(const double (&x)[4][3], cons
   const double m1 = (mu - lambda * lnJ) * detFi;      // (mu - lambda ln J)/J
   const double vm = vol * m1;
   const double mJ = (vol * mu) * Jd;                  // vol mu J
-  double S[3][3];                                     // vol sigma
-  S[0][0] = mJ * (c11 * c22 - c12 * c12) - vm;
-  S[1][1] = mJ * (c00 * c22 - c02 * c02) - vm;
-  S[2][2] = mJ * (c00 * c11 - c01 * c01) - vm;
-  S[0][1] = S[1][0] = mJ * (c02 * c12 - c01 * c22);
-  S[0][2] = S[2][0] = mJ * (c01 * c12 - c02 * c11);
-  S[1][2] = S[2][1] = mJ * (c01 * c02 - c00 * c12);
+  // T = vol (sigma + m1 I) = vol mu J adj(C): the isotropic part -vm of vol sigma cancels against vm I, so
+  //   t_b = vol (m1 g_b + sigma g_b) = T g_b
+  // is nine operations per node instead of fifteen (round 4; the evaluation is the FP64-bound third of a chunk).  The
+  // diagonal product goes LAST into each fused chain: in a stress-free state the off-diagonal entries are exact zeros and
+  // T_ii = vol mu J = vm to the bit, so t_b = round(vm g_b) exactly and the residual -(t_a - round(vm g_a)) of
+  // g_consume_diag is still zero to the bit there.
+  const double a00 = c11 * c22 - c12 * c12, a11 = c00 * c22 - c02 * c02, a22 = c00 * c11 - c01 * c01;
+  const double a01 = c02 * c12 - c01 * c22, a02 = c01 * c12 - c02 * c11, a12 = c01 * c02 - c00 * c12;
   if (DOK) {
+    const double T00 = mJ * a00, T11 = mJ * a11, T22 = mJ * a22, T01 = mJ * a01, T02 = mJ * a02, T12 = mJ * a12;
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int i = 0; i < 3; ++i) R[b * 3 + i] = g[b][i];
-    // t_b = round(vm g_b) + vol sigma g_b, every node alike and without fused multiply-add, so that the residual
-    // -(t_a - round(vm g_a)) of a stress-free state is zero to the bit (g_consume_diag)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-        R[12 + b * 3 + i] = __dadd_rn(__dmul_rn(vm, g[b][i]), S[i][0] * g[b][0] + S[i][1] * g[b][1] + S[i][2] * g[b][2]);
+    for (int b = 0; b < 4; ++b) {
+      R[12 + b * 3 + 0] = fma(T00, g[b][0], fma(T01, g[b][1], T02 * g[b][2]));
+      R[12 + b * 3 + 1] = fma(T11, g[b][1], fma(T01, g[b][0], T12 * g[b][2]));
+      R[12 + b * 3 + 2] = fma(T22, g[b][2], fma(T02, g[b][0], T12 * g[b][1]));
+    }
     R[24] = (vol * lambda) * detFi;                   // vol lambda/J
     R[25] = vm;
   } else {
+    double S[3][3];                                   // vol sigma
+    S[0][0] = mJ * a00 - vm; S[1][1] = mJ * a11 - vm; S[2][2] = mJ * a22 - vm;
+    S[0][1] = S[1][0] = mJ * a01; S[0][2] = S[2][0] = mJ * a02; S[1][2] = S[2][1] = mJ * a12;
 #pragma unroll
     for (int b = 1; b < 4; ++b)
 #pragma unroll
@@ -313,11 +319,15 @@ __device__ __forceinline__ double lintet_record_a5(const double (&x)[4][3], cons
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int i = 0; i < 3; ++i) R[b * 3 + i] = g[b][i];
+    // t_b = (vol sigma + vm I) g_b, the diagonal product last (lintet_record_nh: nine operations per node, and
+    // t_b = round(vm g_b) to the bit where vol sigma is an exact zero)
+    const double T00 = S[0][0] + vm, T11 = S[1][1] + vm, T22 = S[2][2] + vm;
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-        R[12 + b * 3 + i] = __dadd_rn(__dmul_rn(vm, g[b][i]), S[i][0] * g[b][0] + S[i][1] * g[b][1] + S[i][2] * g[b][2]);
+    for (int b = 0; b < 4; ++b) {
+      R[12 + b * 3 + 0] = fma(T00, g[b][0], fma(S[0][1], g[b][1], S[0][2] * g[b][2]));
+      R[12 + b * 3 + 1] = fma(T11, g[b][1], fma(S[0][1], g[b][0], S[1][2] * g[b][2]));
+      R[12 + b * 3 + 2] = fma(T22, g[b][2], fma(S[0][2], g[b][0], S[1][2] * g[b][1]));
+    }
     R[24] = vd * lambda;                                  // vol lambda / J
     R[25] = vm;
   } else {

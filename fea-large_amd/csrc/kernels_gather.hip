@@ -29,9 +29,6 @@
 //      stores: every CSR value is written exactly once.
 // Every sum has a fixed order: the assembly is bitwise reproducible.
 #include "gather_device.h"
-#ifndef G_BATCH
-#define G_BATCH 0
-#endif
 // Persistent form: a workgroup walks a run of consecutive chunks and keeps the next chunk's loads in flight under
 // the current chunk's arithmetic --
 //   * the map words and the node coordinates of chunk i+1 (and the node ids of chunk i+2) are requested before the
@@ -62,6 +59,7 @@ void k_assemble_gather(GatherArgs A, int run_len)
   const size_t stride = (size_t)A.lay.stride;
   const unsigned char *rec = A.maps + (size_t)(A.chunk0 + chunk) * stride;
   const bool node_lane = t < A.lay.max_nodes;
+  const int wslot = __builtin_amdgcn_readfirstlane(t >> 6);   // this wave's slot in the workgroup, provably wave-uniform
 
   // the Gauss weight is read ONCE: a load inside the loop would be the youngest memory operation when the state
   // phase needs it, and waiting for it waits for every prefetch issued before it (in-order counter)
@@ -95,6 +93,10 @@ void k_assemble_gather(GatherArgs A, int run_len)
     double2 ca0, ca1, cc0, cc1;
     const GMaps m = mn;
     const int nrows = h.r1 - h.r0;
+    // contribution words THIS wave's block threads walk: the host sorts the blocks by list length and balances the waves
+    // over the SIMDs (gather.cpp), so a wave stops at the depth of its own longest list, not of the chunk's
+    const unsigned wdw = wslot < 4 ? h.wdepth[0] : (wslot < 8 ? h.wdepth[1] : h.wdepth[2]);     // (no dynamic index: the header stays in scalar registers)
+    const int wd = wslot < G_TASK_THREADS / 64 ? (int)((wdw >> (8 * (wslot & 3))) & 255u) : 0;
     rec = A.maps + (size_t)(A.chunk0 + chunk) * stride;
 
     __builtin_amdgcn_s_setprio(PRIO_STATE);
@@ -148,7 +150,10 @@ void k_assemble_gather(GatherArgs A, int run_len)
       // the header of the next chunk as a VECTOR load (lane l holds word l, read back with v_readlane): a scalar
       // load shares its counter with the LDS, and every barrier's wait for the LDS would wait for it as well
       hword = reinterpret_cast<const int *>(rec1)[t & 15];
-      g_load_maps<DOK, DOF>(A.lay, G_ABL(64) ? A.maps + (size_t)A.chunk0 * stride : rec1, t, mn);
+      // the interior bricks of a structured block have IDENTICAL map words (chunk-local indices only): the host flags a
+      // chunk whose successor's words equal its own, and the words then simply stay in their registers -- no loads, no
+      // HBM traffic (the maps were 0.6 of the 0.8 GB a launch fetched), a shorter issue queue at the end of this phase
+      if (!(h.flags & 1) || G_ABL(64)) g_load_maps<DOK, DOF>(A.lay, G_ABL(64) ? A.maps + (size_t)A.chunk0 * stride : rec1, t, mn);
       const size_t n1 = (size_t)(node_lane ? node1 : 0);
       ca0 = *reinterpret_cast<const double2 *>(A.x + n1 * 4); ca1.x = A.x[n1 * 4 + 2];
       cc0 = *reinterpret_cast<const double2 *>(A.X0 + n1 * 4); cc1.x = A.X0[n1 * 4 + 2];
@@ -161,29 +166,20 @@ void k_assemble_gather(GatherArgs A, int run_len)
 
     __builtin_amdgcn_s_setprio(PRIO_GATHER);
     // ---- phase 2: block sums and residual partials, out of the records
-    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, accd = 0;
     if (DOK && t < h.noffd) {
       // the reads of the next contribution are in flight while the current one is summed; a list of n words is
       // walked as 2n entries whatever it holds (empty entries read the all-zero record)
 #define G_FETCH(w) (G_ABL(4) ? g_fetch_cheap(sT, w) : g_fetch(sT, w))
-#define G_APPLY(r) do { if (G_ABL(2)) g_apply_cheap(r, acc); else g_apply(r, acc); } while (0)
-#if G_BATCH
-      switch (min(h.depth, FEA_G_REGW)) {                    // the reads of up to four contributions in flight before the first is summed
-      case 1: g_gather_batch<0, 1>(sT, m.cw, acc); break;
-      case 2: g_gather_batch<0, 2>(sT, m.cw, acc); break;
-      case 3: g_gather_batch<0, 2>(sT, m.cw, acc); g_gather_batch<2, 1>(sT, m.cw, acc); break;
-      case 4: g_gather_batch<0, 2>(sT, m.cw, acc); g_gather_batch<2, 2>(sT, m.cw, acc); break;
-      default: break;
-      }
-#else
+#define G_APPLY(r) do { if (G_ABL(2)) g_apply_cheap(r, acc); else g_apply(r, acc, accd); } while (0)
 #pragma unroll
       for (int k = 0; k < FEA_G_REGW; ++k)
-        if (k < h.depth) { { const GRead r = G_FETCH(m.cw[k] & 0xFFFFu); G_APPLY(r); } { const GRead r = G_FETCH(m.cw[k] >> 16); G_APPLY(r); } }
-#endif
-      for (int k = FEA_G_REGW; k < h.depth; ++k) {          // blocks with more than 8 contributions (unstructured meshes)
+        if (k < wd) { { const GRead r = G_FETCH(m.cw[k] & 0xFFFFu); G_APPLY(r); } { const GRead r = G_FETCH(m.cw[k] >> 16); G_APPLY(r); } }
+      for (int k = FEA_G_REGW; k < wd; ++k) {               // blocks with more than 8 contributions (unstructured meshes)
         const unsigned w = reinterpret_cast<const unsigned *>(rec + A.lay.o_clist)[k * FEA_G_THREADS + t];
-        g_consume(sT, w & 0xFFFFu, acc); g_consume(sT, w >> 16, acc);
+        g_consume(sT, w & 0xFFFFu, acc, accd); g_consume(sT, w >> 16, acc, accd);
       }
+      g_finish(acc, accd);
     }
     double dg[6] = {0, 0, 0, 0, 0, 0};
     double fa[3] = {0, 0, 0};
@@ -214,8 +210,10 @@ void k_assemble_gather(GatherArgs A, int run_len)
     double *sF = DOK ? sT + ((A.lay.max_tile * 9 + 3) & ~1) : sT;
     if (DOK && t < h.noffd && !G_ABL(16)) {
       const int bpos = (int)(m.tpos & 0xFFFFu), mpos = (int)(m.tpos >> 16);
+      if (bpos != 0xFFFF) {                            // (a thread slot the host left without a block)
 #pragma unroll
-      for (int q = 0; q < 9; ++q) sK[bpos * 9 + q] = acc[q];
+        for (int q = 0; q < 9; ++q) sK[bpos * 9 + q] = acc[q];
+      }
       if (mpos != 0xFFFF) {                            // K_ba = K_ab' (fea_solver.c:1249 relies on the same symmetry)
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -242,6 +240,7 @@ void k_assemble_gather(GatherArgs A, int run_len)
     // stores just issued included (s_waitcnt vmcnt(0): measured, a third of the chunk time).  Here only the
     // prefetches themselves are younger, they were requested a state + gather phase ago, and nothing ever waits
     // for a store.
+    G_STAMP(4);
     asm volatile("" : : "v"(mn.eids), "v"(mn.tpos), "v"(mn.cw[0]), "v"(mn.cw[1]), "v"(mn.cw[2]), "v"(mn.cw[3]),
                  "v"(mn.vw[0]), "v"(mn.vw[1]), "v"(mn.kd), "v"(mn.vb), "v"(mn.ve), "v"(node1), "v"(hword));
     if (more && node_lane) {                           // next chunk's coordinates: the tile has been dead since the state phase
@@ -253,8 +252,10 @@ void k_assemble_gather(GatherArgs A, int run_len)
     hn.noffd = __builtin_amdgcn_readlane(hword, 6); hn.depth = __builtin_amdgcn_readlane(hword, 7);
     hn.nvthr = __builtin_amdgcn_readlane(hword, 8); hn.vdepth = __builtin_amdgcn_readlane(hword, 9);
     hn.ddepth = __builtin_amdgcn_readlane(hword, 10);
+    hn.wdepth[0] = (unsigned)__builtin_amdgcn_readlane(hword, 11); hn.wdepth[1] = (unsigned)__builtin_amdgcn_readlane(hword, 12);
+    hn.wdepth[2] = (unsigned)__builtin_amdgcn_readlane(hword, 13); hn.flags = __builtin_amdgcn_readlane(hword, 14);
     G_BARRIER();
-    G_STAMP(4);
+    G_STAMP(5);
     if (!DOK) {                                        // f_a = sum of the row's partials
       const int ft = t;
       const int fr = ft / 3, fi = ft - 3 * fr;
@@ -264,7 +265,6 @@ void k_assemble_gather(GatherArgs A, int run_len)
         A.f[(size_t)(h.r0 + fr) * 3 + fi] = a;
       }
     }
-    G_STAMP(5);
     if (DOK && DOF && t >= G_TASK_THREADS && (t & 3) == 0 && t - G_TASK_THREADS < 4 * nrows) {
       // the row's residual, stored with the rows (after the wait for the prefetches above: no store before it)
       double *fo = A.f + (size_t)(h.r0 + ((t - G_TASK_THREADS) >> 2)) * 3;
@@ -276,24 +276,11 @@ void k_assemble_gather(GatherArgs A, int run_len)
       const int total = h.nb * 9;
       if (odd && t == 0) Kd[0] = sK[0];
       const int npair = (total - odd) >> 1;
-#if G_BATCH
-      int j = t;
-      for (; j + FEA_G_THREADS < npair; j += 2 * FEA_G_THREADS) {     // two LDS reads in flight, then their two stores
-        const int p = odd + 2 * j;
-        const double2 v0 = *reinterpret_cast<const double2 *>(sK + p), v1 = *reinterpret_cast<const double2 *>(sK + p + 2 * FEA_G_THREADS);
-        *reinterpret_cast<double2 *>(Kd + p) = v0; *reinterpret_cast<double2 *>(Kd + p + 2 * FEA_G_THREADS) = v1;
-      }
-      for (; j < npair; j += FEA_G_THREADS) {
-        const int p = odd + 2 * j;
-        *reinterpret_cast<double2 *>(Kd + p) = *reinterpret_cast<const double2 *>(sK + p);
-      }
-#else
       for (int j = t; j < npair; j += FEA_G_THREADS) {
         const int p = odd + 2 * j;
         if (G_ABL(32) && j >= 64) break;               // timing experiment: one 1 KB store per chunk instead of all rows
         *reinterpret_cast<double2 *>(Kd + p) = *reinterpret_cast<const double2 *>(sK + p);
       }
-#endif
       if (((total - odd) & 1) && t == 0) Kd[total - 1] = sK[total - 1];
     }
     G_BARRIER();                                       // the tile is free again (its reads are done)
@@ -414,7 +401,7 @@ int launch_assemble_gather(feahip_ctx *c, bool doK, bool doF)
       fprintf(stderr, "[gather stamps] in-kernel clock %.0f MHz (s_memtime / s_memrealtime x 100 MHz over a run), run = %.0f shader cycles for %d chunks\n",
               sum[0][7] > 0 ? 100.0 * sum[0][6] / sum[0][7] : 0.0, sum[0][6] / nruns, run_len);
       for (int w = 0; w < NW; w += (NW > 4 ? 5 : 1))
-        fprintf(stderr, "[gather stamps K=%d F=%d wave %d, per chunk] state %.0f  prefetch+gather %.0f  barrier %.0f  tile %.0f  diag+drain %.0f  writeout %.0f cycles\n",
+        fprintf(stderr, "[gather stamps K=%d F=%d wave %d, per chunk] state %.0f  gather %.0f  barrier B %.0f  tile writes %.0f  wait for the prefetched words + coordinates + barrier C %.0f  rows out (+ barrier D) %.0f cycles\n",
                 (int)doK, (int)doF, w, sum[w][0] / c->ngchunks, sum[w][1] / c->ngchunks, sum[w][2] / c->ngchunks, sum[w][3] / c->ngchunks,
                 sum[w][4] / c->ngchunks, sum[w][5] / c->ngchunks);
     }

@@ -84,6 +84,7 @@ ABI = {
     "feahip_host_rank_mesh": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _dp, C.POINTER(C.c_longlong), _ip, _ip,
                               C.POINTER(C.c_longlong), _ip],
     "feahip_copy_bandwidth": [C.c_void_p, C.c_longlong, _dp],
+    "feahip_copy_bandwidth_detail": [C.c_void_p, C.c_longlong, _dp],
     "feahip_device_layout": [C.c_void_p, C.POINTER(C.c_longlong)],
     "feahip_host_numbering": [C.c_int, C.c_int, C.c_int, _ip, _dp, _ip],
 }
@@ -493,6 +494,13 @@ class FeaSolver:
         v = C.c_double(0)
         self._chk(self._lib.feahip_copy_bandwidth(self._ctx, nbytes, C.byref(v)))
         return v.value
+
+    def copy_bandwidth_detail(self, nbytes=1 << 30):
+        """The same four ways: [one 16-byte load in flight per lane, four in flight per lane, hipMemcpyDtoDAsync,
+        four in flight non-temporal]."""
+        v = (C.c_double * 4)()
+        self._chk(self._lib.feahip_copy_bandwidth_detail(self._ctx, nbytes, v))
+        return [float(x) for x in v]
 
     def device_layout(self):
         o = (C.c_longlong * 4)()

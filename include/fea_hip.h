@@ -58,7 +58,7 @@ enum {
                               per chunk element and shared through LDS, the
                               blocks of a (row, element, column) pair summed
                               over the Gauss points in registers              */
-  FEAHIP_ASM_GATHER = 8    /* linear tets: a 256-thread workgroup owns a run
+  FEAHIP_ASM_GATHER = 8    /* linear tets: a 1024-thread workgroup owns a run
                               of block rows; every element touching them is
                               evaluated once into an LDS record, one thread
                               per off-diagonal block then sums that block's
@@ -335,6 +335,11 @@ int feahip_time_kernel(feahip_ctx *ctx, int what, int warmup, int iters,
  * on the context's device and stream: the copy bandwidth of this box, to quote
  * roofline fractions against next to the data-sheet peak.     */
 int feahip_copy_bandwidth(feahip_ctx *ctx, long long bytes, double *gbytes_per_s);
+/* The same measured four ways (the call above reports the best): out4[0] one
+ * 16-byte load in flight per lane (grid-stride), out4[1] four independent
+ * 16-byte loads in flight per lane, out4[2] hipMemcpyDtoDAsync, out4[3] as
+ * [1] with non-temporal loads and stores.                                   */
+int feahip_copy_bandwidth_detail(feahip_ctx *ctx, long long bytes, double *out4);
 /* device addresses of K, the column indices and the two SpMV vectors (for
  * the alignment column of a bandwidth report): out4                         */
 int feahip_device_layout(feahip_ctx *ctx, long long *out4);

@@ -8,7 +8,7 @@ for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), 
         k = row.get("Kernel_Name", "?").split("(")[0][:60]
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, cs in sorted(acc.items()):
-    if not any(t in k for t in ("assemble", "spmv", "cg_")):
+    if not any(t in k for t in ("assemble", "spmv", "cg_", "state10")):
         continue
     print(k)
     for c, v in sorted(cs.items()):
