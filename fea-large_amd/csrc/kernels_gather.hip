@@ -154,10 +154,14 @@ void k_assemble_gather(GatherArgs A, int run_len)
       // chunk whose successor's words equal its own, and the words then simply stay in their registers -- no loads, no
       // HBM traffic (the maps were 0.6 of the 0.8 GB a launch fetched), a shorter issue queue at the end of this phase
       if (!(h.flags & 1) || G_ABL(64)) g_load_maps<DOK, DOF>(A.lay, G_ABL(64) ? A.maps + (size_t)A.chunk0 * stride : rec1, t, mn);
-      const size_t n1 = (size_t)(node_lane ? node1 : 0);
-      ca0 = *reinterpret_cast<const double2 *>(A.x + n1 * 4); ca1.x = A.x[n1 * 4 + 2];
-      cc0 = *reinterpret_cast<const double2 *>(A.X0 + n1 * 4); cc1.x = A.X0[n1 * 4 + 2];
-      node1 = reinterpret_cast<const int *>(A.maps + (size_t)(A.chunk0 + c2) * stride + A.lay.o_nodes)[t & (FEA_G_MAX_NODES - 1)];
+      // coordinates and node ids: the waves that hold node slots only (a wave-uniform branch: the other waves issue
+      // nothing -- every load a wave issues here queues behind the previous chunk's rows)
+      if (wslot < FEA_G_MAX_NODES / 64) {
+        const size_t n1 = (size_t)(node_lane ? node1 : 0);
+        ca0 = *reinterpret_cast<const double2 *>(A.x + n1 * 4); ca1.x = A.x[n1 * 4 + 2];
+        cc0 = *reinterpret_cast<const double2 *>(A.X0 + n1 * 4); cc1.x = A.X0[n1 * 4 + 2];
+        node1 = reinterpret_cast<const int *>(A.maps + (size_t)(A.chunk0 + c2) * stride + A.lay.o_nodes)[t & (FEA_G_MAX_NODES - 1)];
+      }
     }
 
     G_LDS_DRAIN();                                     // the asm record stores
