@@ -194,6 +194,7 @@ def main():
                     "--quadratic), or bx,by,bz")
     ap.add_argument("--cpu-single-only", action="store_true", help="skip the one-oracle-copy-per-core CPU baseline")
     ap.add_argument("--no-tet10", action="store_true", help="skip the small TET10 leg of extras")
+    ap.add_argument("--no-off-lattice", action="store_true", help="skip the off-lattice legs of extras (jittered + permuted block, tiled TetGen deck)")
     ap.add_argument("--pcg-variant", type=int, default=-1, help="-1: the context's default; 0: two-reduction PCG; 1: single-reduction PCG")
     args = ap.parse_args()
     if args.cpu_sample is None:
@@ -355,6 +356,7 @@ def main():
         "node_numbering": ("caller: " + ("lexicographic (x fastest, z, y slowest)" if brick is None else "bricks of %dx%dx%d nodes" % brick) +
                            "; library: " + ("renumbered to compact cells (csrc/renumber.cpp)" if renumbered else "the caller's ids kept")),
         "verified": verified,
+        "gather_maps": solver.assembly_stats(),
         "copy_bandwidth_GBps": copy_gbps,
         "copy_bandwidth_GBps_by_method": (dict(zip(("one_16B_load_per_lane", "four_16B_loads_in_flight", "hipMemcpyDtoDAsync", "four_16B_nontemporal"), copy3))
                                           if copy3 else None),
@@ -384,7 +386,60 @@ def main():
             s10.close()
         except Exception as e:                      # noqa: BLE001
             tet10 = {"failed": str(e)}
+    # ---- off the lattice: (i) the SAME block with every node displaced by a deterministic
+    # pseudo-random +-0.2 spacings (0.3 inverts Kuhn tetrahedra) and the caller's ids randomly permuted; (ii) the
+    # reference's TetGen deck brick_fine.sexp (22 934 TET10, deck order kept as sexp_loader.c:170-215 does), 48 copies
+    # side by side = 1.1 M TET10 / 5 GP.  Which kernel AUTO takes, element evaluations per element, time, roofline fraction.
+    off = None
+    if world == 1 and not args.quadratic and not args.hex and not args.no_off_lattice:
+        off = {}
+
+        def leg(name, d, what):
+            try:
+                t0 = time.perf_counter()
+                s2 = feahip.FeaSolver(d, device=local)
+                s2.set_nodes(mesh.deformed_state(d.nodes))
+                s2.create_stiffness_and_residual(); s2.sync()
+                bad = s2.update_state()
+                t_set = time.perf_counter() - t0
+                z2 = s2.sizes()
+                for _ in range(30):
+                    s2.create_stiffness_and_residual()
+                s2.sync()
+                ms = s2.time_kernel(0, warmup=5, iters=20)
+                B2 = algorithmic_bytes(z2["npe"], z2["E"], z2["N"], z2["nnzb"] * 9)
+                iu = s2.assembly_in_use()
+                off[name] = {"workload": what, "elements": z2["E"], "nodes": z2["N"], "scalar_nnz": z2["nnzb"] * 9,
+                             "assembly_in_use": {feahip.ASM_GATHER: "GATHER", feahip.ASM_STAGED: "STAGED", feahip.ASM_SHARED: "SHARED",
+                                                 feahip.ASM_ROWOWNER: "ROWOWNER"}.get(iu, str(iu)),
+                             "gather_maps": s2.assembly_stats(), "inverted_gauss_points": bad,
+                             "assembly_ms": ms, "elements_per_s": z2["E"] / (ms * 1e-3), "algorithmic_GBps": B2 / (ms * 1e-3) / 1e9,
+                             "hbm_frac": B2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "setup_s": t_set,
+                             "renumbered_by_library": not np.array_equal(s2.node_numbering(), np.arange(z2["N"]))}
+                s2.close()
+            except Exception as e:                  # noqa: BLE001
+                off[name] = {"failed": str(e)}
+
+        leg("jittered_permuted_block", mesh.jitter_permute(deck, amp=0.2, seed=4),
+            f"the timed block ({E_total} TET4), nodes displaced by +-0.2 spacings (seeded), caller ids randomly permuted")
+        try:
+            import gzip
+            import shutil
+            import tempfile
+            src = os.path.join(ROOT, "tests", "golden", "decks", "brick_fine.sexp.gz")
+            with tempfile.TemporaryDirectory() as td:
+                pth = os.path.join(td, "brick_fine.sexp")
+                with gzip.open(src, "rb") as fi, open(pth, "wb") as fo:
+                    shutil.copyfileobj(fi, fo)
+                bf = feahip.Deck.load(pth)
+            bf.presc_node = (bf.presc_node - 1).astype(np.int32)     # the deck's boundary ids are 1-based
+            leg("brick_fine_tiled", mesh.tiled(bf, (4, 4, 3)),
+                "the reference's TetGen deck brick_fine.sexp (22 934 TET10 / 5 GP, 34 070 nodes, deck order), 4 x 4 x 3 copies side by side")
+        except Exception as e:                      # noqa: BLE001
+            off["brick_fine_tiled"] = {"failed": str(e)}
     traffic, traffic_src = pmc_traffic(args, world, kernel)
+    if off is not None:
+        extras["off_lattice"] = off
     if tet10 is not None:
         extras["tet10"] = tet10
     out = {

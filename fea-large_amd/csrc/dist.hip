@@ -31,6 +31,12 @@ int install_plan(feahip_ctx *c, const ShardPlan &plan)
       else if (lo >= 0) { if (k - lo > best_hi - best_lo) { best_lo = lo; best_hi = k; } lo = -1; }
     }
     c->ichunk_lo = best_lo; c->ichunk_hi = best_hi;
+    // what the overlapped exchange relies on, checked outright: no chunk of the interior range reads a halo column
+    for (int k = best_lo; k < best_hi; ++k) {
+      const int r0 = c->h_chunk[c->chunk0 + k], r1 = c->h_chunk[c->chunk0 + k + 1];
+      for (int q = c->h_rowptr[r0]; q < c->h_rowptr[r1]; ++q)
+        if (c->h_colidx[q] < plan.row0 || c->h_colidx[q] >= plan.row1) { c->err = "interior chunk range reads a halo column"; return FEAHIP_ESTATE; }
+    }
   }
   c->peer = plan.peer; c->send_off = plan.send_off; c->recv_off = plan.recv_off;
   c->nsend = (int)plan.send_idx.size(); c->nrecv = (int)plan.recv_idx.size();

@@ -1,5 +1,16 @@
 // feahip_api.hip -- extern "C" entry points of include/fea_hip.h.
 #include "feahip_internal.h"
+
+#undef hipMalloc
+hipError_t feahip_device_malloc(void **p, size_t bytes)
+{
+  static int fill = -1;
+  if (fill < 0) { const char *e = getenv("FEAHIP_TEST_NAN_ALLOC"); fill = e && atoi(e) > 0 ? 1 : 0; }
+  const hipError_t rc = hipMalloc(p, bytes);
+  if (rc == hipSuccess && fill && bytes) { (void)hipMemset(*p, 0xFF, bytes); (void)hipDeviceSynchronize(); }   // (the fill lands before anything a non-blocking stream does)
+  return rc;
+}
+#define hipMalloc(p, bytes) feahip_device_malloc((void **)(p), (bytes))
 #include "amg.h"
 #include <algorithm>
 #include <cmath>
@@ -811,15 +822,13 @@ extern "C" int feahip_matrix_nnz(feahip_ctx *c, long long *nnz)
   return FEAHIP_OK;
 }
 
-extern "C" int feahip_get_matrix_yale(feahip_ctx *c, int *offsets, int *indexes, double *values)
+template <class OFF>
+static int matrix_yale(feahip_ctx *c, OFF *offsets, int *indexes, double *values)
 {
-  CTX_GUARD(c);
-  if (!offsets || !indexes || !values) return FEAHIP_EINVAL;
-  if ((long long)c->nnzb * 9 > 0x7FFFFFFFLL) { c->err = "matrix too large for 32-bit Yale offsets"; return FEAHIP_EINVAL; }
   std::vector<double> K((size_t)c->nnzb * 9, 0.0);               // rows of other ranks read as zero
   int rc = get_vec(c, c->d_K_base, K.data() + (size_t)c->kb0 * 9, (size_t)(c->kb1 - c->kb0) * 9);
   if (rc) return rc;
-  int pos = 0;
+  size_t pos = 0;
   offsets[0] = 0;
   std::vector<std::pair<int, int>> row;                           // (caller's column node, block) of one row, sorted by column
   for (int a = 0; a < c->N; ++a) {                                // a: the CALLER's node; its row lives at the library id
@@ -835,10 +844,29 @@ extern "C" int feahip_get_matrix_yale(feahip_ctx *c, int *offsets, int *indexes,
           values[pos] = K[(size_t)cb.second * 9 + 3 * i + j];
           pos++;
         }
-      offsets[3 * a + i + 1] = pos;
+      offsets[3 * a + i + 1] = (OFF)pos;
     }
   }
   return FEAHIP_OK;
+}
+
+extern "C" int feahip_get_matrix_yale(feahip_ctx *c, int *offsets, int *indexes, double *values)
+{
+  CTX_GUARD(c);
+  if (!offsets || !indexes || !values) return FEAHIP_EINVAL;
+  if ((long long)c->nnzb * 9 > 0x7FFFFFFFLL) {                   // sp_matrix_yale keeps int offsets: refused, not wrapped
+    c->err = "matrix too large for 32-bit Yale offsets (use feahip_get_matrix_yale64)";
+    return FEAHIP_EINVAL;
+  }
+  return matrix_yale<int>(c, offsets, indexes, values);
+}
+
+extern "C" int feahip_get_matrix_yale64(feahip_ctx *c, long long *offsets, int *indexes, double *values)
+{
+  CTX_GUARD(c);
+  if (!offsets || !indexes || !values) return FEAHIP_EINVAL;
+  if ((long long)c->N * 3 > 0x7FFFFFFFLL) { c->err = "more than 2^31 dofs: column indexes do not fit"; return FEAHIP_EINVAL; }
+  return matrix_yale<long long>(c, offsets, indexes, values);
 }
 
 extern "C" int feahip_spmv(feahip_ctx *c, const double *x, double *y)
@@ -961,6 +989,16 @@ extern "C" int feahip_copy_bandwidth(feahip_ctx *c, long long bytes, double *gby
   const int rc = feahip_copy_bandwidth_detail(c, bytes, v);
   if (rc) return rc;
   *gbytes_per_s = std::max(std::max(v[0], v[1]), std::max(v[2], v[3]));
+  return FEAHIP_OK;
+}
+
+extern "C" int feahip_assembly_stats(feahip_ctx *c, double *o)
+{
+  if (!c || !o) return FEAHIP_EINVAL;
+  o[0] = c->have_gather ? c->gather_evals_per_element : 0.0;
+  o[1] = c->have_gather ? (double)c->ngchunks : 0.0;
+  o[2] = c->have_gather ? (double)c->gather_same_words : 0.0;
+  o[3] = c->have_gather ? (double)c->gather_bytes : 0.0;
   return FEAHIP_OK;
 }
 

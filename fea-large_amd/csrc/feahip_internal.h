@@ -8,6 +8,13 @@
 #include <vector>
 #include "../../include/fea_hip.h"
 
+// Every device allocation of the library goes through here.  FEAHIP_TEST_NAN_ALLOC=1 (test knob: results must not
+// change) fills a fresh allocation with 0xFF bytes -- NaN as a double or a float, -1 as an integer -- so that a read of
+// memory the library never wrote shows in the results instead of depending on what the allocator handed back
+// (GPU AddressSanitizer is not available on the target pool).
+hipError_t feahip_device_malloc(void **p, size_t bytes);
+#define hipMalloc(p, bytes) feahip_device_malloc((void **)(p), (bytes))
+
 #define FEA_MAX_NPE 10
 #define FEA_MAX_GAUSS 27
 
@@ -100,6 +107,7 @@ struct feahip_ctx {
   struct GatherLayout *gather_lay = nullptr;
   long long gather_bytes = 0;
   double gather_evals_per_element = 0;   // element evaluations the gather chunks make per element this rank touches
+  int gather_same_words = 0;             // gather chunks whose map words equal their predecessor's
   // the same for 10-node tetrahedra (kernels_gather10.hip); shares d_gmaps / ngchunks / gather_row0.. with the above
   struct Gather10Layout *gather10_lay = nullptr;
   int *d_g10_elist = nullptr;            // this rank's elements

@@ -325,6 +325,7 @@ int ensure_gather(feahip_ctx *c)
   c->gather_row0 = c->row0; c->gather_row1 = c->row1;
   c->gather_bytes = (long long)hg.blob.size();
   c->gather_evals_per_element = hg.distinct_elems ? (double)hg.total_evals / (double)hg.distinct_elems : 0.0;
+  c->gather_same_words = hg.same_as_previous;
   c->have_gather = true;
   return FEAHIP_OK;
 }

@@ -10,6 +10,7 @@
 // 3N doubles.  All reductions are two-stage with a fixed grid and a fixed
 // order, so repeated runs give identical bits.
 #include "feahip_internal.h"
+#include <map>
 
 // ------------------------------------------------------------------------
 // small device helpers
@@ -704,6 +705,13 @@ static void enq_spmv_dot(feahip_ctx *c, const double *xv, double *yv, const doub
 // ------------------------------------------------------------------------
 // transports
 // ------------------------------------------------------------------------
+// test knob of the in-process transport: the halo rows of a vector become NaN (GroupTransport::exchange_begin)
+__global__ void k_halo_poison(int n, const int *__restrict__ idx, int stride, double *__restrict__ v)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * 3) v[(size_t)idx[i / 3] * stride + i % 3] = __builtin_nan("");
+}
+
 static double *halo_vec(feahip_ctx *c, int which, int &stride)
 {
   stride = (which == 2) ? 4 : 3;
@@ -769,6 +777,83 @@ struct GroupTransport : Transport {
                                         sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToDevice, b->stream));
       }
     for (auto *c : R) { (void)hipSetDevice(c->device); enq_unpack(c, which); }
+    return FEAHIP_OK;
+  }
+  // The same exchange in two halves, as the RCCL transport runs it (dist.hip): pack on the context's stream, copies and
+  // unpack on a communication stream per context, events instead of host synchronisation -- so that the in-process
+  // tests execute the choreography the multi-process runs rely on: between begin and end the context's stream
+  // multiplies the rows that touch no halo column WHILE the halo rows arrive.
+  // FEAHIP_TEST_POISON_HALO=1 (test knob; results must not change): begin() overwrites the halo rows with NaN and the
+  // copies are held back until everything enqueued between begin and end has run -- a product that reads a halo row
+  // too early then reads NaN every time, not only when a race goes the wrong way.
+  bool poison = false, poison_read = false;
+  int which_pending = 0;
+  std::map<feahip_ctx *, hipEvent_t> ev_interior;      // test knob only: "everything enqueued up to exchange_end has run"
+  ~GroupTransport() override { for (auto &kv : ev_interior) (void)hipEventDestroy(kv.second); }
+  static int ensure_streams(feahip_ctx *c)
+  {
+    if (!c->comm_stream) {
+      FEA_HIP_CHECK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+      FEA_HIP_CHECK(c, hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
+      FEA_HIP_CHECK(c, hipEventCreateWithFlags(&c->ev_unpacked, hipEventDisableTiming));
+    }
+    return FEAHIP_OK;
+  }
+  int copies_and_unpack(std::vector<feahip_ctx *> &R, int which)
+  {
+    for (auto *b : R) {                            // receiver by receiver, on ITS communication stream
+      (void)hipSetDevice(b->device);
+      for (size_t kb = 0; kb < b->peer.size(); ++kb) {
+        feahip_ctx *a = R[(size_t)b->peer[kb]];
+        size_t k = 0;
+        while (k < a->peer.size() && a->peer[k] != b->rank) ++k;
+        const int n = b->recv_off[kb + 1] - b->recv_off[kb];
+        if (k == a->peer.size() || a->send_off[k + 1] - a->send_off[k] != n) { b->err = "halo plans of two ranks disagree"; return FEAHIP_ECOMM; }
+        FEA_HIP_CHECK(b, hipStreamWaitEvent(b->comm_stream, a->ev_packed, 0));
+        if (poison) FEA_HIP_CHECK(b, hipStreamWaitEvent(b->comm_stream, ev_interior[a], 0));
+        if (n > 0)
+          FEA_HIP_CHECK(b, hipMemcpyAsync(b->d_recv_buf + (size_t)3 * b->recv_off[kb], a->d_send_buf + (size_t)3 * a->send_off[k],
+                                          sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToDevice, b->comm_stream));
+      }
+      // the receiver's own stream has packed (and, under the test knob, poisoned and multiplied) before its halo rows change
+      FEA_HIP_CHECK(b, hipStreamWaitEvent(b->comm_stream, poison ? ev_interior[b] : b->ev_packed, 0));
+      int stride; double *v = halo_vec(b, which, stride);
+      feahip_enq_unpack_on(b, v, stride, b->comm_stream);
+      FEA_HIP_CHECK(b, hipEventRecord(b->ev_unpacked, b->comm_stream));
+    }
+    return FEAHIP_OK;
+  }
+  int exchange_begin(std::vector<feahip_ctx *> &R, int which) override
+  {
+    if (!poison_read) { const char *e = getenv("FEAHIP_TEST_POISON_HALO"); poison = e && atoi(e) > 0; poison_read = true; }
+    int rc;
+    for (auto *c : R) {
+      (void)hipSetDevice(c->device);
+      if ((rc = ensure_streams(c))) return rc;
+      if (poison && !ev_interior.count(c)) { hipEvent_t e; FEA_HIP_CHECK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_interior[c] = e; }
+    }
+    for (auto *c : R) {
+      (void)hipSetDevice(c->device);
+      // the send buffer is free once every receiver of the previous exchange has copied it out
+      for (int pk : c->peer) FEA_HIP_CHECK(c, hipStreamWaitEvent(c->stream, R[(size_t)pk]->ev_unpacked, 0));
+      enq_pack(c, which);
+      if (poison && c->nrecv > 0) {
+        int stride; double *v = halo_vec(c, which, stride);
+        hipLaunchKernelGGL(k_halo_poison, dim3((c->nrecv * 3 + 255) / 256), dim3(256), 0, c->stream, c->nrecv, c->d_recv_idx, stride, v);
+      }
+      FEA_HIP_CHECK(c, hipEventRecord(c->ev_packed, c->stream));
+    }
+    which_pending = which;
+    return poison ? FEAHIP_OK : copies_and_unpack(R, which);
+  }
+  int exchange_end(std::vector<feahip_ctx *> &R) override
+  {
+    if (poison) {                                  // the copies start only now: behind everything enqueued since begin()
+      for (auto *c : R) { (void)hipSetDevice(c->device); FEA_HIP_CHECK(c, hipEventRecord(ev_interior[c], c->stream)); }
+      const int rc = copies_and_unpack(R, which_pending);
+      if (rc) return rc;
+    }
+    for (auto *c : R) { (void)hipSetDevice(c->device); FEA_HIP_CHECK(c, hipStreamWaitEvent(c->stream, c->ev_unpacked, 0)); }
     return FEAHIP_OK;
   }
   int allreduce(std::vector<feahip_ctx *> &R, int slot, int n) override

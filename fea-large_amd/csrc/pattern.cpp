@@ -77,7 +77,9 @@ int build_host_pattern(int N, int E, int npe, const int *conn, HostPattern &hp,
   for (int a = 0; a < N; ++a) {
     maxlen = std::max(maxlen, hp.rowptr[a + 1]);
     tot += hp.rowptr[a + 1];
-    if (tot > 0x7FFFFFFFLL / 9) { err = "pattern exceeds 32-bit block indexing"; return FEAHIP_EINVAL; }
+    // block numbers are ints; VALUE indices (block x 9 + entry) are size_t everywhere they are formed.  (Until round 4
+    // this refused 2^31 / 9 blocks -- 2^31 scalar non-zeros -- which one rank of eight of BASELINE configs[4] exceeds.)
+    if (tot > 0x7FFFFF00LL) { err = "pattern exceeds 32-bit block indexing"; return FEAHIP_EINVAL; }
     hp.rowptr[a + 1] = (int)tot;
   }
   hp.max_rowlen = maxlen;

@@ -54,6 +54,7 @@ ABI = {
     "feahip_get_shape_gradients": [C.c_void_p, _dp, _dp],
     "feahip_matrix_nnz": [C.c_void_p, C.POINTER(C.c_longlong)],
     "feahip_get_matrix_yale": [C.c_void_p, _ip, _ip, _dp],
+    "feahip_get_matrix_yale64": [C.c_void_p, C.POINTER(C.c_longlong), _ip, _dp],
     "feahip_spmv": [C.c_void_p, _dp, _dp],
     "feahip_set_assembly": [C.c_void_p, C.c_int],
     "feahip_set_preconditioner": [C.c_void_p, C.c_int],
@@ -85,6 +86,7 @@ ABI = {
                               C.POINTER(C.c_longlong), _ip],
     "feahip_copy_bandwidth": [C.c_void_p, C.c_longlong, _dp],
     "feahip_copy_bandwidth_detail": [C.c_void_p, C.c_longlong, _dp],
+    "feahip_assembly_stats": [C.c_void_p, _dp],
     "feahip_device_layout": [C.c_void_p, C.POINTER(C.c_longlong)],
     "feahip_host_numbering": [C.c_int, C.c_int, C.c_int, _ip, _dp, _ip],
 }
@@ -426,6 +428,16 @@ class FeaSolver:
         self._chk(self._lib.feahip_get_matrix_yale(self._ctx, _i(off), _i(idx), _d(val)))
         return off, idx, val
 
+    def matrix_yale64(self):
+        """The same with 64-bit offsets (feahip_get_matrix_yale refuses 2^31 or more scalar non-zeros)."""
+        nnz = C.c_longlong(0)
+        self._chk(self._lib.feahip_matrix_nnz(self._ctx, C.byref(nnz)))
+        off = np.zeros(self.ndof + 1, dtype=np.int64)
+        idx = np.zeros(nnz.value, dtype=np.int32)
+        val = np.zeros(nnz.value)
+        self._chk(self._lib.feahip_get_matrix_yale64(self._ctx, off.ctypes.data_as(C.POINTER(C.c_longlong)), _i(idx), _d(val)))
+        return off, idx, val
+
     def spmv(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         y = np.zeros(self.ndof)
@@ -494,6 +506,13 @@ class FeaSolver:
         v = C.c_double(0)
         self._chk(self._lib.feahip_copy_bandwidth(self._ctx, nbytes, C.byref(v)))
         return v.value
+
+    def assembly_stats(self):
+        """dict: element evaluations per element of the gather chunks, chunks, chunks with their predecessor's map
+        words, map bytes (zeros when another strategy runs)."""
+        v = (C.c_double * 4)()
+        self._chk(self._lib.feahip_assembly_stats(self._ctx, v))
+        return {"evals_per_element": float(v[0]), "chunks": int(v[1]), "chunks_with_predecessors_words": int(v[2]), "map_bytes": int(v[3])}
 
     def copy_bandwidth_detail(self, nbytes=1 << 30):
         """The same four ways: [one 16-byte load in flight per lane, four in flight per lane, hipMemcpyDtoDAsync,

@@ -17,6 +17,7 @@ half-spacing grid; local order 4:(0,1) 5:(1,2) 6:(0,2) 7:(0,3) 8:(1,3) 9:(2,3)
 as fea_solver.c:1287-1300.
 """
 import itertools
+import copy
 import math
 
 import numpy as np
@@ -255,3 +256,52 @@ def deformed_state(nodes, k1=1.1, wiggle=1e-3):
     X = nodes
     u = wiggle * np.sin(2 * np.pi * X[:, 0]) * np.sin(np.pi * (X[:, 1] - 1.0) / 3.0) * np.sin(2 * np.pi * X[:, 2])
     return x + u[:, None]
+
+
+def jitter_permute(deck, amp=0.2, seed=4, spacing=None):
+    """The same mesh off the lattice: every node displaced by a deterministic pseudo-random vector of at most `amp`
+    spacings per axis (amp <= 0.2 keeps every Kuhn tetrahedron's volume positive) and the node ids randomly
+    permuted -- what a mesh generator's output looks like to the library: no structure in the ids, no exact lattice
+    in the coordinates.  Prescribed displacements follow their nodes."""
+    rng = np.random.default_rng(seed)
+    N = len(deck.nodes)
+    if spacing is None:
+        e = deck.elements[: min(len(deck.elements), 4096)]
+        d = np.abs(deck.nodes[e[:, 0]] - deck.nodes[e[:, 1]])
+        spacing = np.array([np.median(d[:, k][d[:, k] > 0]) if (d[:, k] > 0).any() else 0.0 for k in range(3)])
+        spacing[spacing == 0] = spacing[spacing > 0].min()
+    nodes = deck.nodes + amp * spacing * (2.0 * rng.random((N, 3)) - 1.0)
+    new_id = rng.permutation(N)                          # new id of old node
+    out = copy.copy(deck)
+    out.nodes = np.empty_like(nodes)
+    out.nodes[new_id] = nodes
+    out.elements = np.ascontiguousarray(new_id[deck.elements].astype(np.int32))
+    out.presc_node = np.ascontiguousarray(new_id[deck.presc_node].astype(np.int32)) if len(deck.presc_node) else deck.presc_node
+    return out
+
+
+def tiled(deck, copies):
+    """cx x cy x cz translated copies of a deck's mesh side by side (separate bodies: no shared nodes), the copies'
+    nodes and elements appended in order -- a way to time a mesh generator's mesh at a size the generator's own
+    output does not have.  Prescribed nodes are replicated with their values."""
+    cx, cy, cz = copies
+    ext = deck.nodes.max(axis=0) - deck.nodes.min(axis=0)
+    N = len(deck.nodes)
+    nodes, elements, pn, pt, pv = [], [], [], [], []
+    k = 0
+    for iz in range(cz):
+        for iy in range(cy):
+            for ix in range(cx):
+                nodes.append(deck.nodes + 1.05 * ext * np.array([ix, iy, iz]))
+                elements.append(deck.elements + k * N)
+                if len(deck.presc_node):
+                    pn.append(deck.presc_node + k * N); pt.append(deck.presc_type); pv.append(deck.presc_values)
+                k += 1
+    out = copy.copy(deck)
+    out.nodes = np.ascontiguousarray(np.concatenate(nodes))
+    out.elements = np.ascontiguousarray(np.concatenate(elements).astype(np.int32))
+    if pn:
+        out.presc_node = np.ascontiguousarray(np.concatenate(pn).astype(np.int32))
+        out.presc_type = np.ascontiguousarray(np.concatenate(pt).astype(np.int32))
+        out.presc_values = np.ascontiguousarray(np.concatenate(pv))
+    return out

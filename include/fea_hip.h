@@ -286,6 +286,11 @@ int feahip_get_shape_gradients(feahip_ctx *ctx, double *grads, double *detj);
 int feahip_matrix_nnz(feahip_ctx *ctx, long long *nnz);
 int feahip_get_matrix_yale(feahip_ctx *ctx, int *offsets, int *indexes,
                            double *values);
+/* The same with 64-bit offsets.  feahip_get_matrix_yale REFUSES (FEAHIP_EINVAL, feahip_last_error says why) a matrix
+ * of 2^31 or more scalar non-zeros instead of wrapping its int offsets: one rank of eight of BASELINE configs[4]
+ * (50M 10-node tetrahedra) already holds 2.2e9.                                */
+int feahip_get_matrix_yale64(feahip_ctx *ctx, long long *offsets, int *indexes,
+                             double *values);
 /* y = K x with host vectors (test hook for the SpMV kernel)                 */
 int feahip_spmv(feahip_ctx *ctx, const double *x, double *y);
 
@@ -346,6 +351,11 @@ int feahip_device_layout(feahip_ctx *ctx, long long *out4);
 /* sizes the roofline model needs: N, E, npe, G, block rows, blocks, and the
  * bytes of the auxiliary maps the kernels read                              */
 int feahip_sizes(feahip_ctx *ctx, long long *out8);
+/* What the gather strategy's maps look like on this mesh (built on first use; zeros when another strategy runs):
+ * out4[0] element evaluations per element the rank touches (1.75 for a 4x4x4 brick of a Kuhn block), out4[1] gather
+ * chunks, out4[2] chunks whose map words equal their predecessor's (kept in registers by the kernel), out4[3] map
+ * bytes.  For reports (bench.py extras); reference has no counterpart.                                                  */
+int feahip_assembly_stats(feahip_ctx *ctx, double *out4);
 /* the strategy (FEAHIP_ASM_*) the most recent assembly launch ran -- what
  * FEAHIP_ASM_AUTO resolved to on this mesh; FEAHIP_ASM_AUTO before any launch */
 int feahip_assembly_in_use(feahip_ctx *ctx, int *strategy);

@@ -3,6 +3,8 @@ through size-independent properties -- the oracle would need minutes there:
 K symmetric, K.(rigid translation) = 0 before BCs, stress-free reference
 state, residual = -K.u consistency, the uniaxial closed form as the exact FE
 answer (patch test), sharded = unsharded."""
+import os
+
 import numpy as np
 import pytest
 
@@ -187,6 +189,52 @@ def test_tet10_27_point_rule_at_scale():
     s5.close()
 
 
+def test_config4_one_ranks_worth_on_one_gpu(tmp_path):
+    """BASELINE.json configs[4] is 50 577 408 ten-node tetrahedra with the 27-point rule on 8 GPUs: 6 322 176 elements
+    per rank.  The same element count, rule and kernels in ONE context on the one GPU the tests have (the n = 56
+    block: 56 x 336 x 56 cubes): one stiffness + residual assembly, K . translation = 0, symmetry, no inverted Gauss
+    point, f = 0 in the reference state; what the context holds and how long the assembly takes go to a report the
+    round's profiles keep.  The matrix has 2.2e9 scalar non-zeros: the 32-bit Yale getter must refuse, not wrap
+    (fea_solver.c:1491-1506 plugs exactly this element and rule in)."""
+    import json
+    import time
+    import torch
+    deck = mesh.bar_deck(n=56, quadratic=True, gauss=27)
+    assert len(deck.elements) == 6322176
+    free0 = torch.cuda.mem_get_info(0)[0]
+    t0 = time.perf_counter()
+    s = feahip.FeaSolver(deck)
+    s.create_residual_forces()
+    assert np.abs(s.forces()).max() < 1e-9
+    s.set_nodes(mesh.deformed_state(deck.nodes))
+    s.create_stiffness_and_residual(); s.sync()
+    setup_s = time.perf_counter() - t0
+    assert s.update_state() == 0
+    assert s.assembly_in_use() == feahip.ASM_GATHER
+    held = free0 - torch.cuda.mem_get_info(0)[0]
+    z = s.sizes()
+    assert z["nnzb"] * 9 >= 2 ** 31
+    ms = s.time_kernel(0, warmup=1, iters=3)
+    rng = np.random.default_rng(27)
+    a, b = rng.normal(size=s.ndof), rng.normal(size=s.ndof)
+    ya = s.spmv(a)
+    t = np.zeros(s.ndof); t[1::3] = 1.0
+    assert np.abs(s.spmv(t)).max() < 1e-10 * np.abs(ya).max()
+    assert abs(b @ ya - a @ s.spmv(b)) < 1e-10 * abs(b @ ya)
+    with pytest.raises(feahip.FeaHipError):
+        s._chk(s._lib.feahip_get_matrix_yale(s._ctx, feahip._i(np.zeros(4, dtype=np.int32)), feahip._i(np.zeros(4, dtype=np.int32)),
+                                             feahip._d(np.zeros(4))))
+    report = {"workload": "6 322 176 TET10 / 27 GP (one rank of eight of BASELINE configs[4]) in one context", "nodes": z["N"],
+              "scalar_nnz": z["nnzb"] * 9, "device_bytes": int(held), "assembly_ms": ms, "elements_per_s": z["E"] / (ms * 1e-3),
+              "setup_s": setup_s, "gather_maps": s.assembly_stats()}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "config4_one_rank.json"), "w") as fh:
+        json.dump(report, fh)
+    assert held < 120e9                                        # well inside one MI355X (288 GB)
+    s.close()
+
+
 def test_10m_assembly_properties():
     """configs[2]: the headline mesh.  One assembly, checked by K.t = 0,
     symmetry and f = 0 at the reference state."""
@@ -198,6 +246,7 @@ def test_10m_assembly_properties():
     s.set_nodes(mesh.deformed_state(deck.nodes))
     s.create_stiffness_and_residual()
     assert s.update_state() == 0
+    assert s.assembly_in_use() == feahip.ASM_GATHER              # the lexicographic deck, numbered by the library: the gather kernel
     rng = np.random.default_rng(9)
     a, b = rng.normal(size=s.ndof), rng.normal(size=s.ndof)
     yb = s.spmv(b)

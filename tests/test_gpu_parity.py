@@ -451,6 +451,8 @@ def test_brick_fine_one_assembly(decks_dir, tmp_path):
     s.update_nodes_with_bc(1.0)
     s.create_stiffness_and_residual()
     assert s.update_state() == 0                         # no inverted Gauss point with corrected ids
+    assert s.assembly_in_use() == feahip.ASM_GATHER      # the TetGen deck, numbered by the library: state + gather kernels
+    assert s.assembly_stats()["evals_per_element"] < 12.0
     off, idx, val = s.matrix_yale()
     assert len(val) == 8300196                           # scalar nnz of the deck
     # spot-check the block rows of 40 nodes against the sum of the oracle's element matrices of the elements around

@@ -63,6 +63,35 @@ def test_sharded_assembly_is_the_unsharded_one(n, strategy, quadratic):
     g.close(); one.close()
 
 
+@pytest.mark.parametrize("rank_contexts", [False, True])
+@pytest.mark.parametrize("precond", [0, 1])
+def test_interior_product_never_reads_a_halo_row(rank_contexts, precond, monkeypatch):
+    """The single-reduction PCG multiplies the rows that touch no halo column WHILE the halo rows of z travel on the
+    communication stream (exchange_begin ... exchange_end; the default loop of every sharded solve, RCCL included).
+    FEAHIP_TEST_POISON_HALO makes the in-process transport overwrite the halo rows with NaN at exchange_begin and hold
+    the copies back until everything enqueued up to exchange_end has run: if the interior range (install_plan) held a
+    chunk with a halo column, or an event dependency were missing, NaN would reach w and the solve.  It must be the
+    solve of the unpoisoned run, bit for bit."""
+    deck = mesh.bar_deck(dims=(6, 96, 6) if precond else (3, 48, 3))
+
+    def run(n):
+        g = feahip.FeaGroup(deck, n, rank_contexts=rank_contexts)
+        g.each("set_pcg_variant", 1); g.each("set_preconditioner", precond)
+        g.each("update_nodes_with_bc", 1.0); g.each("create_stiffness_and_residual"); g.each("apply_prescribed_bc", 0.0)
+        it, res = g.solve_slae(feahip.PCG_ILU, 1e-15, 20000)
+        u, e = g.gather("solution"), g.energy()
+        g.close()
+        return it, res, u, e
+
+    for n in (2, 3):
+        monkeypatch.delenv("FEAHIP_TEST_POISON_HALO", raising=False)
+        it0, res0, u0, e0 = run(n)
+        monkeypatch.setenv("FEAHIP_TEST_POISON_HALO", "1")
+        it1, res1, u1, e1 = run(n)
+        assert np.isfinite(u1).all() and np.isfinite(res1) and res1 < 1e-14
+        assert it1 == it0 and np.array_equal(u1, u0) and e1 == e0
+
+
 @pytest.mark.parametrize("n,solver", [(2, feahip.PCG_ILU), (3, feahip.CG)])
 def test_sharded_linear_solve(n, solver):
     deck = mesh.bar_deck(dims=(3, 48, 3))

@@ -105,6 +105,36 @@ def _lex_pair(dims=(5, 14, 6), **kw):
 
 
 @pytest.mark.gpu
+def test_jittered_and_permuted_block_against_the_oracle():
+    """The off-lattice leg of bench.py in small: the block's nodes displaced by +-0.2 spacings (seeded) and the caller's
+    ids randomly permuted -- no lattice in the coordinates, no structure in the ids.  The library's numbering still
+    finds compact cells (the gather kernel runs, at the lattice's element evaluations per element), and pattern, K, f
+    and the solve are the oracle's in the CALLER's numbering."""
+    lattice = mesh.bar_deck(dims=(5, 14, 6))
+    deck = mesh.jitter_permute(lattice, amp=0.2, seed=4)
+    assert not np.array_equal(deck.elements, lattice.elements)
+    x = mesh.deformed_state(deck.nodes, k1=1.07)
+    s, o = feahip.FeaSolver(deck), OracleSolver(deck)
+    s.set_nodes(x); o.set_nodes(x)
+    o.update_state(); o.create_stiffness(); o.create_residual_forces()
+    s.create_stiffness_and_residual()
+    assert s.update_state() == 0
+    assert s.assembly_in_use() == feahip.ASM_GATHER
+    s_lat = feahip.FeaSolver(lattice)
+    s_lat.create_stiffness_and_residual()
+    assert s.assembly_stats()["evals_per_element"] == pytest.approx(s_lat.assembly_stats()["evals_per_element"], rel=0.02)
+    s_lat.close()
+    off, idx, val = s.matrix_yale()
+    assert np.array_equal(off, o.offsets()) and np.array_equal(idx, o.indexes())
+    assert rel(val, o.values()) < 1e-12 and rel(s.forces(), o.forces()) < 1e-12
+    s.apply_prescribed_bc(0.0); o.apply_prescribed_bc(0.0)
+    s.solve_slae(feahip.PCG_ILU, 1e-15, 20000)
+    o.solve_slae(feahip.CHOLESKY)
+    assert rel(s.solution(), o.solution()) < 1e-10
+    s.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("model", [feahip.MODEL_COMPRESSIBLE_NEOHOOKEAN, feahip.MODEL_A5])
 def test_renumbered_context_speaks_the_callers_numbering(model):
     """Every node-indexed entry of the ABI on a mesh the library renumbers, against the oracle run on the caller's
