@@ -56,9 +56,10 @@ bool locality_numbering(int N, int E, int npe, const int *conn, const double *X 
   const int a_slow = ax[0], a_mid = ax[1], a_fast = ax[2];
   // spacing per axis from a sample of the elements
   double h[3];
+  std::vector<double> dsample[3];                            // non-zero coordinate differences between the nodes of an element, per axis
   {
     const int stride = std::max(1, E / 200000);
-    std::vector<double> d[3];
+    std::vector<double> (&d)[3] = dsample;
     for (int e = 0; e < E; e += stride)
       for (int p = 0; p < npe; ++p)
         for (int q = p + 1; q < npe; ++q) {
@@ -68,7 +69,65 @@ bool locality_numbering(int N, int E, int npe, const int *conn, const double *X 
             if (v > 1e-9 * ext[k]) d[k].push_back(v);
           }
         }
-    for (int k = 0; k < 3; ++k) { h[k] = median_inplace(d[k]); if (!(h[k] > 0.0)) return false; }
+    for (int k = 0; k < 3; ++k) { std::vector<double> w(d[k]); h[k] = median_inplace(w); if (!(h[k] > 0.0)) return false; }
+  }
+  // A lattice with noise (a structured block whose nodes were moved by a fraction of the spacing).  The median above
+  // is the spacing of an exact lattice only: noise turns the zero differences into small ones and drags it down (10M
+  // block, +-0.2 h: 0.84 h, 0.78 h and 0.50 h on the three axes), cells of four such spacings drift against the node
+  // planes, the chunks stop being bricks and stop repeating (1.93 element evaluations per element instead of 1.73,
+  // 36 056 chunks with no two alike in a row instead of 28 682 with 82 % repeats, 0.80 ms instead of 0.65).  So origin
+  // and spacing of every axis are FITTED to the nodes: from a few candidate spacings (the median; the median of the
+  // upper cluster of the differences; half of it -- the mid-edge planes of 10-node elements) the plane index of every
+  // node k_i = round((x_i - o) / h) and (o, h) by least squares of x_i on k_i, three rounds; a candidate counts when
+  // the nodes DO sit on its planes (rms distance < 0.2 h: uniformly scattered nodes give 0.29) and its planes are IN
+  // USE (nine in ten between the first and the last hold a node: a lattice fits any finer grid as well); the finest
+  // that counts wins.  An exact lattice returns itself, a TetGen mesh keeps the median spacing and the box corner.
+  double lat_o[3] = {lo[0], lo[1], lo[2]};
+  for (int k = 0; k < 3; ++k) {
+    double cand[3] = {h[k], 0.0, 0.0};
+    {
+      std::vector<double> &v = dsample[k];
+      std::vector<double> w(v);
+      const size_t i95 = (size_t)(0.95 * (double)(w.size() - 1));
+      std::nth_element(w.begin(), w.begin() + (long)i95, w.end());
+      const double p95 = w[i95];
+      std::vector<double> up;
+      for (double x : v) if (x > 0.5 * p95) up.push_back(x);
+      if (!up.empty()) { cand[1] = median_inplace(up); cand[2] = 0.5 * cand[1]; }
+    }
+    double best_h = 0.0, best_o = 0.0;
+    for (int ci = 0; ci < 3; ++ci) {
+      double o = lo[k], hh = cand[ci];
+      if (!(hh > 0.0)) continue;
+      bool ok = true;
+      for (int round = 0; round < 3 && ok; ++round) {
+        double sk = 0, sx = 0, skk = 0, skx = 0;
+        for (int a = 0; a < N; ++a) {
+          const double x = X[(size_t)a * 3 + k], q = std::floor((x - o) / hh + 0.5);
+          sk += q; sx += x; skk += q * q; skx += q * x;
+        }
+        const double den = (double)N * skk - sk * sk;
+        if (!(den > 0.0)) { ok = false; break; }
+        const double h2 = ((double)N * skx - sk * sx) / den, o2 = (sx - h2 * sk) / (double)N;
+        if (!(h2 > 0.7 * hh && h2 < 1.4 * hh)) { ok = false; break; }
+        hh = h2; o = o2;
+      }
+      if (!ok) continue;
+      const long long q0 = (long long)std::floor((lo[k] - o) / hh + 0.5), q1 = (long long)std::floor((hi[k] - o) / hh + 0.5);
+      if (q1 - q0 < 1 || q1 - q0 > (1 << 22)) continue;
+      std::vector<char> used((size_t)(q1 - q0 + 1), 0);
+      double ss = 0;
+      for (int a = 0; a < N; ++a) {
+        const double x = X[(size_t)a * 3 + k], r = (x - o) / hh, q = std::floor(r + 0.5);
+        ss += (r - q) * (r - q);
+        const long long qi = (long long)q - q0;
+        if (qi >= 0 && qi <= q1 - q0) used[(size_t)qi] = 1;
+      }
+      long long nused = 0;
+      for (char u : used) nused += u;
+      if (std::sqrt(ss / (double)N) < 0.2 && 10 * nused >= 9 * (q1 - q0 + 1) && (best_h == 0.0 || hh < best_h)) { best_h = hh; best_o = o + hh * (double)q0; }
+    }
+    if (best_h > 0.0) { h[k] = best_h; lat_o[k] = best_o; }
   }
   int cn[3];                                                  // nodes of a cell along x, y, z
   cn[a_fast] = cell[0]; cn[a_slow] = cell[1]; cn[a_mid] = cell[2];
@@ -80,7 +139,7 @@ bool locality_numbering(int N, int E, int npe, const int *conn, const double *X 
     bool ok = true;
     for (int k = 0; k < 3; ++k) {
       cs[k] = h[k] * cn[k] * scale;                           // cell size
-      org[k] = lo[k] - 0.5 * h[k] * scale;                    // node planes of a lattice sit inside the cells, not on their faces
+      org[k] = lat_o[k] - 0.5 * h[k] * scale;                 // node planes of a lattice sit inside the cells, not on their faces
       nc[k] = (long long)std::floor((hi[k] - org[k]) / cs[k]) + 1;
       if (nc[k] < 1 || nc[k] > (1 << 18)) ok = false;
     }

@@ -249,7 +249,7 @@ int feahip_host_assembly_digest(int n_nodes, int n_elems, int npe, const int *el
 /* The reference keeps the nodes in deck order (sexp_loader.c:170-215) and its
  * dof index is node * 3 + axis (fea_solver.c:377-384).  The kernels here own
  * runs of consecutive block rows, so feahip_create numbers the nodes itself
- * (compact cells of ~16 nodes, cells in slabs across the longest axis;
+ * (compact cells of 4 x 4 x 4 nodes (48 half-grid nodes for 10-node elements), cells in slabs across the longest axis;
  * csrc/renumber.cpp) and works in that numbering.  Every entry of this header
  * that takes or returns node-indexed data translates: the caller passes and
  * receives its OWN node ids and dof indices, bit-exactly -- elements,
