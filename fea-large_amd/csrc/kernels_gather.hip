@@ -372,7 +372,19 @@ int launch_assemble_gather(feahip_ctx *c, bool doK, bool doF)
   static int ncu_of[64];
   int &ncu = ncu_of[c->device & 63];
   if (ncu <= 0) { hipDeviceProp_t p; ncu = (hipGetDeviceProperties(&p, c->device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256; }
-  const int run_len = run_env ? run_env : (FEA_G_BIG == 1 ? std::max(1, (c->ngchunks + 2 * ncu - 1) / (2 * ncu)) : 16);
+  // One workgroup is resident per CU: with k runs per CU a launch lasts ceil(runs / CUs) rounds of run_len chunks.  Two runs
+  // per CU even out the lighter boundary chunks on a whole mesh (28 682 chunks: 2 x 57); a rank of eight has 3 585 chunks
+  // and 2 x 8 = 16 chunk times where one run of 15 does -- whichever of k = 1, 2 gives the shorter launch is taken.
+  int run_len = 16;
+  if (run_env) run_len = run_env;
+  else if (FEA_G_BIG == 1) {
+    long best = -1;
+    for (int k = 2; k >= 1; --k) {
+      const int rl = std::max(1, (c->ngchunks + k * ncu - 1) / (k * ncu)), nr = (c->ngchunks + rl - 1) / rl;
+      const long cost = (long)((nr + ncu - 1) / ncu) * rl;
+      if (best < 0 || cost < best) { best = cost; run_len = rl; }
+    }
+  }
   const int nruns = (c->ngchunks + run_len - 1) / run_len;
   const dim3 grid((nruns + 7) & ~7), blk(FEA_G_THREADS);
   // LDS: coordinates (48 bytes per node slot) | element records, later the K tile (+1 double of alignment slack) and the residual partials
