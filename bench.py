@@ -111,6 +111,37 @@ print(json.dumps({"E": len(deck.elements), "dt": time.perf_counter() - t0, "late
 """
 
 
+_WORKER_OMP = r"""
+import json, sys, time
+sys.path[:0] = [sys.argv[1], sys.argv[2]]
+import mesh
+from oracle_binding import OracleSolver
+n, quadratic, model, threads = int(sys.argv[3]), sys.argv[4] == "1", int(sys.argv[5]), int(sys.argv[6])
+deck = mesh.bar_deck(n=n, quadratic=quadratic, model=model)
+o = OracleSolver(deck)
+o.set_nodes(mesh.deformed_state(deck.nodes))
+o.assemble_coloured(threads)                      # threads started, pages touched
+t0 = time.perf_counter()
+ncol = o.assemble_coloured(threads)
+print(json.dumps({"E": len(deck.elements), "dt": time.perf_counter() - t0, "colours": ncol}))
+"""
+
+
+def cpu_baseline_openmp(n_sample, quadratic, model, cores):
+    """ONE problem on all host cores: the oracle's loops with the elements coloured (no two elements of a colour share
+    a node) and every colour an OpenMP parallel loop -- SURVEY.md 8(d)(ii).  A child process, started before the GPU is
+    touched (OMP_NUM_THREADS set for it alone)."""
+    import subprocess
+    args = [sys.executable, "-c", _WORKER_OMP, os.path.join(ROOT, "fea-large_amd"), os.path.join(ROOT, "tests"),
+            str(n_sample), "1" if quadratic else "0", str(model), str(cores)]
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="false")
+    pr = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600, env=env)
+    r = json.loads(pr.stdout.strip().splitlines()[-1])
+    return {"value": r["E"] / r["dt"], "unit": "elements/s", "cores": cores, "kind": "port",
+            "sample": f"{r['E']} elements of the same bar in ONE oracle context, {r['colours']} colours, every colour an OpenMP parallel loop "
+                      f"over {cores} threads (oracle/fea_oracle.c orc_assemble_coloured), state+stiffness+residual, {r['dt']:.1f} s"}
+
+
 def cpu_baseline_all_cores(n_sample, quadratic, model, cores):
     """The same single-threaded oracle, one independent copy of the sample block per host core, all timed
     together: the reference is single-threaded by construction, so this is what the box's cores
@@ -209,13 +240,17 @@ def main():
     import feahip
     import mesh
     model = feahip.MODEL_COMPRESSIBLE_NEOHOOKEAN if args.model == "neohookean" else feahip.MODEL_A5
-    cpu_all = None
+    cpu_all = cpu_omp = None
     if world == 1 and args.cpu_sample > 0 and not args.cpu_single_only:
         # before anything touches the GPU: child processes, one oracle copy per host core (at most 16)
         try:
             cpu_all = cpu_baseline_all_cores(args.cpu_sample, args.quadratic, model, min(16, os.cpu_count() or 1))
         except Exception as e:                      # noqa: BLE001
             print(f"all-cores CPU baseline skipped: {e}", file=sys.stderr)
+        try:
+            cpu_omp = cpu_baseline_openmp(args.cpu_sample, args.quadratic, model, min(16, os.cpu_count() or 1))
+        except Exception as e:                      # noqa: BLE001
+            print(f"OpenMP CPU baseline skipped: {e}", file=sys.stderr)
     import torch
     if world != args.gpus:
         if rank == 0:
@@ -548,6 +583,8 @@ def main():
             cpu_all["unit"] = "elements/s"
             cpu_all["note"] = "independent copies of the same sample, one single-threaded oracle per core, timed together"
             out["cpu_baseline"]["all_cores"] = cpu_all
+        if cpu_omp is not None:
+            out["cpu_baseline"]["all_cores_one_problem_openmp"] = cpu_omp
     emit()
     solver.close()
     if world > 1:

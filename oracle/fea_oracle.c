@@ -7,6 +7,9 @@
  * the evaluation order of the reference line it cites.
  */
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 #include "fea_oracle.h"
@@ -792,6 +795,85 @@ void orc_create_residual_forces(orc_solver *s)
         }
     }
   }
+}
+
+/* ------------------------------------------------------------------------ */
+/* All host cores on ONE problem ("OpenMP over coloured         */
+/* elements"): the reference is single-threaded by construction; this is what  */
+/* its loops give when the elements are coloured so that no two elements of a  */
+/* colour share a node (no two threads then touch the same matrix row or force */
+/* entry) and every colour is a parallel loop.  State, stiffness and residual  */
+/* of an element in one visit.  Summation order inside an entry follows the    */
+/* colours, not the element numbers: equal to orc_update_state +               */
+/* orc_create_stiffness + orc_create_residual_forces to rounding.  A baseline  */
+/* for bench.py, not a checker.  Returns the number of colours (<= 0: failed). */
+int orc_assemble_coloured(orc_solver *s, int nthreads)
+{
+  const int npe = s->npe, E = s->E, N = s->ndof / 3;
+  int e, k, ncol = 0;
+  int *colour = (int *)malloc(sizeof(int) * (size_t)E);
+  /* greedy colouring: the smallest colour none of the element's nodes has seen; per node a bit set of seen colours */
+  unsigned long long *seen = (unsigned long long *)calloc((size_t)N, sizeof(unsigned long long));
+  if (!colour || !seen) { free(colour); free(seen); return -1; }
+  for (e = 0; e < E; ++e) {
+    const int *c = s->conn + (size_t)e * npe;
+    unsigned long long used = 0;
+    int col = 0;
+    for (k = 0; k < npe; ++k) used |= seen[c[k]];
+    while (col < 64 && ((used >> col) & 1ull)) ++col;
+    if (col >= 64) { free(colour); free(seen); return -2; }      /* more than 64 colours: not a mesh this is meant for */
+    colour[e] = col;
+    for (k = 0; k < npe; ++k) seen[c[k]] |= 1ull << col;
+    if (col + 1 > ncol) ncol = col + 1;
+  }
+  free(seen);
+  /* elements grouped by colour */
+  int *first = (int *)calloc((size_t)ncol + 1, sizeof(int)), *list = (int *)malloc(sizeof(int) * (size_t)E);
+  if (!first || !list) { free(colour); free(first); free(list); return -1; }
+  for (e = 0; e < E; ++e) first[colour[e] + 1]++;
+  for (k = 0; k < ncol; ++k) first[k + 1] += first[k];
+  {
+    int *fill = (int *)malloc(sizeof(int) * (size_t)ncol);
+    for (k = 0; k < ncol; ++k) fill[k] = first[k];
+    for (e = 0; e < E; ++e) list[fill[colour[e]]++] = e;
+    free(fill);
+  }
+  memset(s->values, 0, sizeof(double) * (size_t)s->nnz);
+  memset(s->forces, 0, sizeof(double) * (size_t)s->ndof);
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+  (void)nthreads;
+#endif
+  for (k = 0; k < ncol; ++k) {
+    int q;
+#pragma omp parallel for schedule(static)
+    for (q = first[k]; q < first[k + 1]; ++q) {
+      const int el = list[q];
+      const int *c = s->conn + (size_t)el * npe;
+      int g, a, i, j;
+      for (g = 0; g < s->G; ++g) shape_gradients_eg(s, s->x, el, g);
+      for (g = 0; g < s->G; ++g) graddef_stress_eg(s, el, g);
+      local_constitutive_part(s, el);
+      local_initial_stress_part(s, el);
+      for (g = 0; g < s->G; ++g) {                              /* the residual loop of orc_create_residual_forces */
+        size_t eg = (size_t)el * s->G + g;
+        const double *gr = s->grads + eg * 3 * npe;
+        const double *sig = s->stresses + eg * 9;
+        if (!s->have_grads[eg]) continue;
+        for (a = 0; a < npe; ++a)
+          for (i = 0; i < 3; ++i) {
+            double sum = 0.0;
+            for (j = 0; j < 3; ++j) sum += sig[3 * i + j] * gr[j * npe + a];
+            sum *= fabs(s->detJ[eg]);
+            sum *= s->tb.weight[g];
+            s->forces[c[a] * 3 + i] += -sum;
+          }
+      }
+    }
+  }
+  free(colour); free(first); free(list);
+  return ncol;
 }
 
 /* ======================================================================== */

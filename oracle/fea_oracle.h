@@ -114,6 +114,10 @@ double    *orc_forces(orc_solver *s);
 double    *orc_solution(orc_solver *s);
 
 void orc_create_stiffness(orc_solver *s);       /* fea_solver.c:873-883   */
+/* state + stiffness + residual of every element with the elements coloured (no two of a colour share a node) and each
+ * colour a parallel loop over `nthreads` host threads (<= 0: the OpenMP default): the all-cores CPU baseline of bench.py.
+ * Returns the number of colours. */
+int  orc_assemble_coloured(orc_solver *s, int nthreads);
 void orc_create_residual_forces(orc_solver *s); /* fea_solver.c:863-870   */
 void orc_update_nodes_with_bc(orc_solver *s, double lambda);    /* :1281  */
 void orc_apply_prescribed_bc(orc_solver *s, double lambda);     /* :1200  */

@@ -62,6 +62,8 @@ def lib():
                      "orc_restore_stiffness"):
             getattr(L, name).argtypes = [C.c_void_p]
             getattr(L, name).restype = None
+        L.orc_assemble_coloured.argtypes = [C.c_void_p, C.c_int]
+        L.orc_assemble_coloured.restype = C.c_int
         L.orc_update_nodes_with_bc.argtypes = [C.c_void_p, C.c_double]
         L.orc_apply_prescribed_bc.argtypes = [C.c_void_p, C.c_double]
         L.orc_update_nodes_with_solution.argtypes = [C.c_void_p, _dp]
@@ -217,6 +219,14 @@ class OracleSolver:
 
     def solution(self):
         return self._view(self._L.orc_solution, (self.ndof,))
+
+    def assemble_coloured(self, nthreads=0):
+        """State + stiffness + residual with the elements coloured and every colour a parallel loop over the host's
+        threads (OpenMP): the all-cores CPU baseline.  Returns the number of colours."""
+        nc = self._L.orc_assemble_coloured(self._p, nthreads)
+        if nc <= 0:
+            raise RuntimeError(f"orc_assemble_coloured failed ({nc})")
+        return nc
 
     def create_stiffness(self):
         self._L.orc_create_stiffness(self._p)

@@ -174,3 +174,24 @@ def test_tet4_extension_patch_test():
     A = deck.nodes.min(axis=0)
     expect = A + (deck.nodes - A) * np.array([k2, k1, k2])
     assert np.abs(o.nodes() - expect).max() < 1e-12
+
+
+@pytest.mark.parametrize("quadratic", [False, True])
+def test_coloured_parallel_assembly_is_the_serial_one(quadratic):
+    """bench.py's all-cores CPU baseline (the oracle's loops with the elements coloured and every colour an OpenMP
+    parallel loop) against the oracle's serial loops: the same K and f to rounding (the order of the
+    additions inside an entry follows the colours), on 1, 3 and all threads."""
+    import mesh
+    deck = mesh.bar_deck(dims=(3, 8, 4), quadratic=quadratic)
+    x = mesh.deformed_state(deck.nodes, k1=1.06)
+    o = OracleSolver(deck)
+    o.set_nodes(x)
+    o.update_state(); o.create_stiffness(); o.create_residual_forces()
+    K, f = o.values().copy(), o.forces().copy()
+    for nt in (1, 3, 0):
+        p = OracleSolver(deck)
+        p.set_nodes(x)
+        ncol = p.assemble_coloured(nt)
+        assert 4 <= ncol <= 64
+        assert np.abs(p.values() - K).max() < 1e-13 * np.abs(K).max()
+        assert np.abs(p.forces() - f).max() < 1e-13 * max(np.abs(f).max(), 1e-300)
