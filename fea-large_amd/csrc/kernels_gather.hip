@@ -29,6 +29,9 @@
 //      stores: every CSR value is written exactly once.
 // Every sum has a fixed order: the assembly is bitwise reproducible.
 #include "gather_device.h"
+#ifndef G_NT_ROWS
+#define G_NT_ROWS 1                // the rows of K as non-temporal stores (measurement switch)
+#endif
 // Persistent form: a workgroup walks a run of consecutive chunks and keeps the next chunk's loads in flight under
 // the current chunk's arithmetic --
 //   * the map words and the node coordinates of chunk i+1 (and the node ids of chunk i+2) are requested before the
@@ -283,7 +286,11 @@ void k_assemble_gather(GatherArgs A, int run_len)
       for (int j = t; j < npair; j += FEA_G_THREADS) {
         const int p = odd + 2 * j;
         if (G_ABL(32) && j >= 64) break;               // timing experiment: one 1 KB store per chunk instead of all rows
+#if G_NT_ROWS
+        __builtin_nontemporal_store(*reinterpret_cast<const g_v2d *>(sK + p), reinterpret_cast<g_v2d *>(Kd + p));   // written once, read by other kernels only
+#else
         *reinterpret_cast<double2 *>(Kd + p) = *reinterpret_cast<const double2 *>(sK + p);
+#endif
       }
       if (((total - odd) & 1) && t == 0) Kd[total - 1] = sK[total - 1];
     }

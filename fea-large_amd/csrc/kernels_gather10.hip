@@ -127,6 +127,15 @@ struct G10Args {
 #define T_STAMP(i) do { } while (0)
 #endif
 
+typedef double t_v2d __attribute__((ext_vector_type(2)));
+#ifndef T_NT_ROWS
+#define T_NT_ROWS 1
+#endif
+#if T_NT_ROWS
+#define T_NT_STORE(ptr, v) do { const t_v2d nt_ = {(v).x, (v).y}; __builtin_nontemporal_store(nt_, reinterpret_cast<t_v2d *>(ptr)); } while (0)
+#else
+#define T_NT_STORE(ptr, v) do { *reinterpret_cast<double2 *>(ptr) = (v); } while (0)
+#endif
 #define T_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); \
                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
 
@@ -414,12 +423,13 @@ void k_assemble_gather10(G10Args A, int run_len)
           const int j = odd + 2 * i;
           const double2 v0 = *reinterpret_cast<const double2 *>(sT + j), v1 = *reinterpret_cast<const double2 *>(sT + j + 2 * FEA_Q_THREADS),
                         v2 = *reinterpret_cast<const double2 *>(sT + j + 4 * FEA_Q_THREADS), v3 = *reinterpret_cast<const double2 *>(sT + j + 6 * FEA_Q_THREADS);
-          *reinterpret_cast<double2 *>(Kd + j) = v0; *reinterpret_cast<double2 *>(Kd + j + 2 * FEA_Q_THREADS) = v1;
-          *reinterpret_cast<double2 *>(Kd + j + 4 * FEA_Q_THREADS) = v2; *reinterpret_cast<double2 *>(Kd + j + 6 * FEA_Q_THREADS) = v3;
+          T_NT_STORE(Kd + j, v0); T_NT_STORE(Kd + j + 2 * FEA_Q_THREADS, v1);      // written once, read by other kernels only: non-temporal
+          T_NT_STORE(Kd + j + 4 * FEA_Q_THREADS, v2); T_NT_STORE(Kd + j + 6 * FEA_Q_THREADS, v3);
         }
         for (; i < npair2; i += FEA_Q_THREADS) {
           const int j = odd + 2 * i;
-          *reinterpret_cast<double2 *>(Kd + j) = *reinterpret_cast<const double2 *>(sT + j);
+          const double2 v = *reinterpret_cast<const double2 *>(sT + j);
+          T_NT_STORE(Kd + j, v);
         }
         if (((total - odd) & 1) && t == 0) Kd[total - 1] = sT[total - 1];
       }
