@@ -158,3 +158,22 @@ def test_plan_covers_every_referenced_column():
                 assert np.array_equal(pl["send"][k], plans[peer]["recv"][kk])
             # slabs across the long axis: only the neighbouring slabs are peers
             assert set(pl["peers"]) <= {r - 1, r + 1}
+
+
+def test_bench_starts_its_own_ranks_and_reports_their_failure():
+    """`python3 bench.py --gpus 2` without torch.distributed.run around it becomes a launcher BEFORE it touches torch or the
+    library: two child ranks with RANK / WORLD_SIZE / MASTER_* set, rank 0's output passed through, the first non-zero
+    return code propagated.  On a host without a GPU every rank leaves with code 2 ("needs an MI355X") -- which is what
+    this checks: the launcher ran, both ranks ran as ranks 0 and 1 of 2, and the failure came back."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("on a GPU box the ranks would run the benchmark itself (profiles/r04_b_bench_gloo2_selflaunch.*)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-sample", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 2
+    assert r.stderr.count("bench.py needs an MI355X") == 2
+    assert "rank 0: 2, rank 1: 2" in r.stderr
