@@ -470,6 +470,9 @@ def main():
             bf.presc_node = (bf.presc_node - 1).astype(np.int32)     # the deck's boundary ids are 1-based
             leg("brick_fine_tiled", mesh.tiled(bf, (4, 4, 3)),
                 "the reference's TetGen deck brick_fine.sexp (22 934 TET10 / 5 GP, 34 070 nodes, deck order), 4 x 4 x 3 copies side by side")
+            leg("brick_fine_corner_tets_tiled", mesh.tiled(mesh.corner_tets(bf), (8, 8, 7)),
+                "the linear tetrahedra on the corner nodes of the same TetGen deck (22 934 TET4 / 1 GP), 8 x 8 x 7 copies side by side: "
+                "an unstructured linear-tet mesh for the headline kernel")
         except Exception as e:                      # noqa: BLE001
             off["brick_fine_tiled"] = {"failed": str(e)}
     traffic, traffic_src = pmc_traffic(args, world, kernel)

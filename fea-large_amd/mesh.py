@@ -305,3 +305,25 @@ def tiled(deck, copies):
         out.presc_type = np.ascontiguousarray(np.concatenate(pt).astype(np.int32))
         out.presc_values = np.ascontiguousarray(np.concatenate(pv))
     return out
+
+
+def corner_tets(deck):
+    """The linear tetrahedra on the corner nodes of a deck of 10-node tetrahedra (local nodes 0-3), the mid-edge nodes
+    dropped and the rest renumbered in order: an unstructured LINEAR-tet mesh out of the reference's TetGen decks, which
+    only come with 10-node elements.  Prescribed nodes that are mid-edge nodes go with them."""
+    from feahip import TETRAHEDRA4
+    corners = np.unique(deck.elements[:, :4])
+    new_id = np.full(len(deck.nodes), -1, dtype=np.int64)
+    new_id[corners] = np.arange(len(corners))
+    out = copy.copy(deck)
+    out.nodes = np.ascontiguousarray(deck.nodes[corners])
+    out.elements = np.ascontiguousarray(new_id[deck.elements[:, :4]].astype(np.int32))
+    out.nodes_per_element = 4
+    out.ele_type = TETRAHEDRA4
+    out.gauss_nodes_count = 1
+    if len(deck.presc_node):
+        keep = new_id[deck.presc_node] >= 0
+        out.presc_node = np.ascontiguousarray(new_id[deck.presc_node[keep]].astype(np.int32))
+        out.presc_type = np.ascontiguousarray(deck.presc_type[keep])
+        out.presc_values = np.ascontiguousarray(deck.presc_values[keep])
+    return out
