@@ -63,7 +63,9 @@ struct AmgHierarchy {
                                          // same 94 iterations on the 10M-tet block, 7 % less time, half the memory
   unsigned long long num_epoch = 0; bool num_bc = false;     // the matrix the numeric part was built for
   int row0 = 0, row1 = 0;                // rows of level 0 this hierarchy covers (the rank's own)
-  double *d_z = nullptr;                 // level-0 output of the V-cycle
+  double *d_z = nullptr;                 // level-0 iterate of the cycle (zero outside the rank's rows)
+  double *result = nullptr;              // where the last cycle left z: d_z, or the context's q when the last sweep is fused
+  bool fused_post = false;               // post-smoothing product and update in one launch (FEAHIP_AMG_FUSED_POST=1; measured 1.6-2.5 % slower per CG iteration than the two launches)
   double *d_pw = nullptr;                // scratch for the power iteration
   long long bytes = 0;
 };

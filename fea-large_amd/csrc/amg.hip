@@ -8,8 +8,9 @@
 // from kernels_solve.hip
 void enq_spmv_arrays(hipStream_t stream, int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx,
                      const double *K, const double *xv, double *yv);
-void enq_spmv_jacobi(hipStream_t stream, int nchunks, const int *chunk, const int *rowptr, const int *colidx, const double *K,
-                     const float *K32, const double *xin, double *xout, const double *r, const double *minv, double omega);
+void enq_spmv_jacobi(hipStream_t stream, int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx, const double *K,
+                     const float *K32, const unsigned short *K16, const double *xin, double *xout, const double *r, const double *minv,
+                     double omega, double *part);
 void enq_spmv_arrays_f32(hipStream_t stream, int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx,
                          const float *K, const double *xv, double *yv);
 void enq_spmv_arrays_bf16(hipStream_t stream, int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx,
@@ -544,6 +545,7 @@ int amg_create(feahip_ctx *c)
   { const char *e = getenv("FEAHIP_AMG_FINE_BITS"); if (e && (atoi(e) == 32 || atoi(e) == 64)) h->fine_bits = atoi(e); }
   { const char *e = getenv("FEAHIP_AMG_OVER"); if (e) h->over = atof(e); }
   { const char *e = getenv("FEAHIP_AMG_GAMMA_FROM"); if (e) h->gamma_from = atoi(e); }
+  { const char *e = getenv("FEAHIP_AMG_FUSED_POST"); h->fused_post = e && atoi(e) != 0; }
   { const char *e = getenv("FEAHIP_AMG_SWEEPS"); if (e) h->coarse_sweeps = atoi(e); }
   // the levels the one-workgroup kernel takes: from the first level below the finest of at most FEA_TAIL_ROWS rows
   h->tail_from = -1;
@@ -584,7 +586,7 @@ int amg_create(feahip_ctx *c)
         FEA_HIP_CHECK(c, hipMalloc((void **)&L.K32, sizeof(float) * ((size_t)L.nnzb * 9 + 4)));
         FEA_HIP_CHECK(c, hipMemset(L.K32, 0, sizeof(float) * ((size_t)L.nnzb * 9 + 4)));
         h->bytes += (long long)(sizeof(float) * (size_t)L.nnzb * 9);
-      } else if ((rc = zeros(c, &L.K, (size_t)L.nnzb * 9, h->bytes))) return rc;
+      } else if ((rc = zeros(c, &L.K, (size_t)L.nnzb * 9 + 2, h->bytes))) return rc;
       if ((rc = zeros(c, &L.r, (size_t)L.N * 3, h->bytes))) return rc;
       if ((rc = zeros(c, &L.x, (size_t)L.N * 3, h->bytes))) return rc;
       if ((rc = zeros(c, &L.y, (size_t)L.N * 3, h->bytes))) return rc;
@@ -733,7 +735,9 @@ static void launch_tail(feahip_ctx *c)
   hipLaunchKernelGGL(k_amg_tail, dim3(1), dim3(FEA_TAIL_T), lds, c->stream, A);
 }
 
-static void amg_cycle(feahip_ctx *c, int l, const double *r, double *x, double *y)
+// returns where the level's result is: x or y (the post-smoothing sweep is fused with its product and writes the other
+// vector); `part`: partial sums of result . r from that last launch (level 0: the CG's r.z), or null
+static double *amg_cycle(feahip_ctx *c, int l, const double *r, double *x, double *y, double *part = nullptr)
 {
   AmgHierarchy *h = H(c);
   AmgLevel &L = h->lv[l];
@@ -744,36 +748,42 @@ static void amg_cycle(feahip_ctx *c, int l, const double *r, double *x, double *
     // coarsest level: product and damped Jacobi update in one launch per sweep, ping-pong between x and y
     double *a = x, *b = y;
     for (int s = 0; s < h->coarse_sweeps; ++s) {
-      enq_spmv_jacobi(c->stream, L.nchunks, L.chunk, L.rowptr, L.colidx, L.K, L.K32, a, b, r, L.minv, L.omega);
+      enq_spmv_jacobi(c->stream, 0, L.nchunks, L.chunk, L.rowptr, L.colidx, L.K, L.K32, nullptr, a, b, r, L.minv, L.omega, nullptr);
       double *t = a; a = b; b = t;
     }
-    return;                                            // an even number of sweeps ends in x
+    return x;                                          // an even number of sweeps ends in x
   }
   if (L.Nc == 0) {
     for (int s = 0; s < h->coarse_sweeps; ++s) {
       level_spmv(c, L, R, x, y);
       hipLaunchKernelGGL(k_smooth_next, GROWS(R), R.a0, R.a1, L.omega, L.minv, r, y, x);
     }
-    return;
+    return x;
   }
   AmgLevel &C = h->lv[l + 1];
   const int gamma = (l < h->gamma_from) ? 1 : h->gamma;
   for (int g = 0; g < gamma; ++g) {
     level_spmv(c, L, R, x, y);
     hipLaunchKernelGGL(k_restrict, G256((C.N / 2) * 16), C.N / 2, L.aptr, L.anodes, L.type, L.doff, r, y, mask, C.r);
+    const double *xc = C.x;
     if (l + 1 == h->tail_from) launch_tail(c);
-    else amg_cycle(c, l + 1, C.r, C.x, C.y);
+    else xc = amg_cycle(c, l + 1, C.r, C.x, C.y);
     // over-correction only where the correction is applied twice: (I - aE)^2 >= 0 for any a <= 2, while a single
     // over-corrected step can flip the sign of the preconditioner on part of the spectrum (seen: 6 492 iterations)
-    hipLaunchKernelGGL(k_prolong, G256(L.N), L.N, L.agg, L.type, L.doff, C.x, mask, gamma >= 2 ? h->over : fmin(h->over, 1.0), x);
+    hipLaunchKernelGGL(k_prolong, G256(L.N), L.N, L.agg, L.type, L.doff, xc, mask, gamma >= 2 ? h->over : fmin(h->over, 1.0), x);
   }
-  level_spmv(c, L, R, x, y);
-  hipLaunchKernelGGL(k_smooth_next, GROWS(R), R.a0, R.a1, L.omega, L.minv, r, y, x);
+  if (!h->fused_post) {
+    level_spmv(c, L, R, x, y);
+    hipLaunchKernelGGL(k_smooth_next, GROWS(R), R.a0, R.a1, L.omega, L.minv, r, y, x);
+    return x;
+  }
+  enq_spmv_jacobi(c->stream, R.ch0, R.nch, L.chunk, L.rowptr, L.colidx, L.K, L.K32, L.K16, x, y, r, L.minv, L.omega, part);
+  return y;
 }
 
-static void amg_vcycle(feahip_ctx *c, const double *r0, double *z0)
+static double *amg_vcycle(feahip_ctx *c, const double *r0, double *z0)
 {
-  amg_cycle(c, 0, r0, z0, c->d_q);
+  return amg_cycle(c, 0, r0, z0, c->d_q);
 }
 
 // ---- interface to the PCG loop (kernels_solve.hip) ---------------------------
@@ -792,10 +802,10 @@ int amg_prepare(feahip_ctx *c)
 }
 
 // z = M^-1 r on the rank's rows (z stays zero elsewhere); q is used as scratch
-double *amg_result(feahip_ctx *c) { return H(c)->d_z; }
+double *amg_result(feahip_ctx *c) { return H(c)->result; }
 double *amg_apply(feahip_ctx *c, const double *r)
 {
   AmgHierarchy *h = H(c);
-  amg_vcycle(c, r, h->d_z);
-  return h->d_z;
+  h->result = amg_vcycle(c, r, h->d_z);
+  return h->result;
 }

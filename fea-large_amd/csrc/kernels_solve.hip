@@ -9,6 +9,7 @@
 // Matrix: block CSR, 3x3 blocks row-major, block columns sorted.  Vectors:
 // 3N doubles.  All reductions are two-stage with a fixed grid and a fixed
 // order, so repeated runs give identical bits.
+#include <type_traits>
 #include "feahip_internal.h"
 #include <map>
 
@@ -183,6 +184,13 @@ int launch_update_nodes_solution(feahip_ctx *c, const double *d_uv)
 // nine values of block kk as doubles.  bf16_t: the block is stored as three rows of four bfloat16 (three values and a
 // pad: 24 bytes, three 8-byte loads instead of nine 2-byte ones)
 struct bf16_t { unsigned short v[4]; };
+#ifndef FEA_SPMV_STAGED
+#define FEA_SPMV_STAGED 1      // bit 0: double matrices, 1: float, 2: bfloat16 (measured: only the 72-byte blocks gain)
+#endif
+typedef double spmv_v2d __attribute__((ext_vector_type(2)));
+#ifndef SPMV_HOIST
+#define SPMV_HOIST 1
+#endif
 template <class TK>
 __device__ __forceinline__ void load_block9(const TK *K, size_t kk, double (&v)[9])
 {
@@ -202,11 +210,22 @@ __device__ __forceinline__ void load_block9<bf16_t>(const bf16_t *K, size_t kk, 
     v[3 * i + 2] = (double)__uint_as_float(w.y << 16);
   }
 }
-template <class TK>
+// JAC: y = x + omega D^-1 (r - K x) instead of y = K x (one damped block-Jacobi sweep fused with its product: the rows of
+// a chunk -- at most FEA_CHUNK_ROWS = 16, i.e. 48 lanes -- exchange their three residual components by shuffles and apply
+// the inverse diagonal block; y must not be x).  dotwith / part: partial sums of y . dotwith in either mode.
+struct SpmvJacobi { const double *r, *minv; double omega; };
+template <class TK, bool JAC = false>
 __device__ __forceinline__ void spmv_body(int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx, const TK *K,
-                                          const double *x, double *y, const double *dotwith, double *part, const int *flag)
+                                          const double *x, double *y, const double *dotwith, double *part, const int *flag,
+                                          const SpmvJacobi J = SpmvJacobi{nullptr, nullptr, 0.0})
 {
-  __shared__ double sP[FEA_WAVES_PER_WG][FEA_CHUNK_BLOCKS * 3];
+  // per wave: the partial products (3 per block); the staged path first holds the chunk's values there
+  constexpr int BB = std::is_same<TK, double>::value ? 72 : (std::is_same<TK, float>::value ? 36 : 24);   // bytes per block
+  static_assert(FEA_CHUNK_ROWS * 3 <= 64, "one lane per (row, component) of a chunk");
+  constexpr int NPMAX = (15 + FEA_CHUNK_BLOCKS * BB + 15) >> 4;                                             // 16-byte pieces of a chunk
+  constexpr bool STAGED = ((FEA_SPMV_STAGED) & (BB == 72 ? 1 : (BB == 36 ? 2 : 4))) != 0;                    // bit per matrix type
+  constexpr int SPD = STAGED ? (2 * NPMAX > FEA_CHUNK_BLOCKS * 3 ? 2 * NPMAX : FEA_CHUNK_BLOCKS * 3) : FEA_CHUNK_BLOCKS * 3;
+  __shared__ __attribute__((aligned(16))) double sP[FEA_WAVES_PER_WG][SPD];
   __shared__ double scratch[5];
   if (flag && flag[0] != 0) return;          // solve already converged (uniform)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -231,13 +250,77 @@ __device__ __forceinline__ void spmv_body(int chunk0, int nchunks, const int *ch
       }
       a0 = wave_sum_all(a0); a1 = wave_sum_all(a1); a2 = wave_sum_all(a2);
       if (lane < 3) {
-        const double acc = lane == 0 ? a0 : lane == 1 ? a1 : a2;
+        double acc = lane == 0 ? a0 : lane == 1 ? a1 : a2;
+        if constexpr (JAC) {
+          const double *rr = J.r + (size_t)r0 * 3;
+          const double t0 = rr[0] - a0, t1 = rr[1] - a1, t2 = rr[2] - a2;
+          const double *m = J.minv + (size_t)r0 * 9 + 3 * lane;
+          acc = x[(size_t)r0 * 3 + lane] + J.omega * (m[0] * t0 + m[1] * t1 + m[2] * t2);
+        }
         y[(size_t)r0 * 3 + lane] = acc;
         if (dotwith) dsum += acc * dotwith[(size_t)r0 * 3 + lane];
       }
       continue;
     }
     double v[2][9], xv[2][3];
+    // lane t < 3 rows sums component t % 3 of row r0 + t / 3 (a chunk has at most FEA_CHUNK_ROWS = 16 rows: one pass);
+    // its block range is loaded here, with everything else, not after the products
+    int kb = 0, ke = 0;
+    if (SPMV_HOIST && lane < (r1 - r0) * 3) { kb = rowptr[r0 + lane / 3] - b0; ke = rowptr[r0 + lane / 3 + 1] - b0; }
+    double jm[3] = {0, 0, 0}, jr = 0, jx = 0;              // JAC: the lane's row of D^-1, r and x, likewise
+    if constexpr (JAC) {
+      if (lane < (r1 - r0) * 3) {
+        const double *m = J.minv + (size_t)(r0 + lane / 3) * 9 + 3 * (lane % 3);
+        jm[0] = m[0]; jm[1] = m[1]; jm[2] = m[2];
+        jr = J.r[(size_t)r0 * 3 + lane]; jx = x[(size_t)r0 * 3 + lane];
+      }
+    }
+    if constexpr (STAGED) {
+      // the chunk's values are one contiguous run of nb blocks: the wave reads it as lane-contiguous 16-byte pieces
+      // (1 KB per load instruction, every cache line looked up once) and the lanes pick their blocks out of LDS.
+      // A lane loading its own 72-byte block touches 36 lines per load instruction, five instructions per block.
+      constexpr int NJ = (NPMAX + 63) / 64;
+      const size_t s0 = (size_t)b0 * BB, a0 = s0 & ~(size_t)15;      // the arrays are 16-byte aligned and padded by 16 bytes
+      const int sh = (int)(s0 - a0), np = (sh + nb * BB + 15) >> 4;
+      const spmv_v2d *Kp = reinterpret_cast<const spmv_v2d *>(reinterpret_cast<const char *>(K) + a0);
+      spmv_v2d *sW = reinterpret_cast<spmv_v2d *>(tP);
+      int col[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { const int k = lane + 64 * h; col[h] = colidx[k < nb ? b0 + k : b0]; }
+      spmv_v2d pc[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ - 1; ++j) { const int p = lane + 64 * j; pc[j] = Kp[p < np ? p : 0]; }
+      if (np > 64 * (NJ - 1)) { const int p = lane + 64 * (NJ - 1); pc[NJ - 1] = Kp[p < np ? p : 0]; }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xv[h][i] = x[(size_t)col[h] * 3 + i];
+#pragma unroll
+      for (int j = 0; j < NJ - 1; ++j) { const int p = lane + 64 * j; if (p < np) sW[p] = pc[j]; }
+      if (np > 64 * (NJ - 1)) { const int p = lane + 64 * (NJ - 1); if (p < np) sW[p] = pc[NJ - 1]; }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = lane + 64 * h;
+        const char *bp = reinterpret_cast<const char *>(tP) + sh + BB * (k < nb ? k : 0);
+        if constexpr (BB == 24) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const uint2 w = reinterpret_cast<const uint2 *>(bp)[i];
+            v[h][3 * i] = (double)__uint_as_float(w.x << 16);
+            v[h][3 * i + 1] = (double)__uint_as_float(w.x & 0xFFFF0000u);
+            v[h][3 * i + 2] = (double)__uint_as_float(w.y << 16);
+          }
+        } else {
+          using TV = typename std::conditional<BB == 72, double, float>::type;
+#pragma unroll
+          for (int q = 0; q < 9; ++q) v[h][q] = (double)reinterpret_cast<const TV *>(bp)[q];
+        }
+      }
+      // (the products below overwrite the staged values: a wave's LDS operations complete in program order, and every
+      // lane has read its blocks by then)
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    } else {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int k = lane + 64 * h;
@@ -247,6 +330,7 @@ __device__ __forceinline__ void spmv_body(int chunk0, int nchunks, const int *ch
       load_block9<TK>(K, (size_t)kk, v[h]);
 #pragma unroll
       for (int i = 0; i < 3; ++i) xv[h][i] = x[(size_t)col * 3 + i];
+    }
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -258,13 +342,32 @@ __device__ __forceinline__ void spmv_body(int chunk0, int nchunks, const int *ch
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    for (int t = lane; t < (r1 - r0) * 3; t += 64) {
-      const int r = r0 + t / 3, i = t % 3;
-      const int kb = rowptr[r] - b0, ke = rowptr[r + 1] - b0;
+    if constexpr (JAC) {
+      const int t = lane, nt = (r1 - r0) * 3;            // <= 48: one pass
+      const int row = r0 + t / 3, i = t % 3;
+      double res = 0.0;
+      if (t < nt) {
+        if (!SPMV_HOIST) { kb = rowptr[row] - b0; ke = rowptr[row + 1] - b0; }
+        double acc = 0;
+        for (int k = kb; k < ke; ++k) acc += tP[k * 3 + i];
+        res = jr - acc;
+      }
+      const double t0 = __shfl(res, lane - i), t1 = __shfl(res, lane - i + 1), t2 = __shfl(res, lane - i + 2);
+      if (t < nt) {
+        const double xn = jx + J.omega * (jm[0] * t0 + jm[1] * t1 + jm[2] * t2);
+        y[(size_t)r0 * 3 + t] = xn;
+        if (dotwith) dsum += xn * dotwith[(size_t)r0 * 3 + t];
+      }
+    } else {
+    const int t = lane;
+    if (t < (r1 - r0) * 3) {
+      const int i = t % 3;
+      if (!SPMV_HOIST) { kb = rowptr[r0 + t / 3] - b0; ke = rowptr[r0 + t / 3 + 1] - b0; }
       double acc = 0;
       for (int k = kb; k < ke; ++k) acc += tP[k * 3 + i];
       y[(size_t)r0 * 3 + t] = acc;
       if (dotwith) dsum += acc * dotwith[(size_t)r0 * 3 + t];
+    }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   }
@@ -299,79 +402,31 @@ void k_spmv_bf16(int chunk0, int nchunks, const int *chunk, const int *rowptr, c
   spmv_body<bf16_t>(chunk0, nchunks, chunk, rowptr, colidx, K, x, y, (const double *)nullptr, (double *)nullptr, (const int *)nullptr);
 }
 
-// One damped block-Jacobi sweep fused with its product: xout = xin + omega D^-1 (r - K xin).  The product is the
-// SpMV above (wave per chunk, same partial products, same order); the rows of a chunk (<= 16, i.e. <= 48 lanes) then
-// exchange their three residual components by shuffles and apply the inverse diagonal block: one launch instead of
-// two, no y vector.  Used for the sweeps on the coarsest level of the multigrid cycle (96 launch pairs per cycle).
+// One damped block-Jacobi sweep fused with its product: xout = xin + omega D^-1 (r - K xin) (spmv_body<TK, true>: same
+// partial products, same order; one launch instead of two, no y vector).  The sweeps on the coarsest level of the
+// multigrid cycle and the post-smoothing of every level; `part`: partial sums of xout . r (the CG's r.z after the last
+// step of a cycle), or null.
 template <class TK>
 __global__ __launch_bounds__(256)
-void k_spmv_jacobi(int nchunks, const int *chunk, const int *rowptr, const int *colidx, const TK *K,
-                   const double *xin, double *xout, const double *r, const double *minv, double omega)
+void k_spmv_jacobi(int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx, const TK *K,
+                   const double *xin, double *xout, const double *r, const double *minv, double omega, double *part)
 {
-  __shared__ double sP[FEA_WAVES_PER_WG][FEA_CHUNK_BLOCKS * 3];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double *tP = sP[wave];
-  for (int ch = blockIdx.x * FEA_WAVES_PER_WG + wave; ch < nchunks; ch += gridDim.x * FEA_WAVES_PER_WG) {
-    const int r0 = chunk[ch], r1 = chunk[ch + 1];
-    const int b0 = rowptr[r0], nb = rowptr[r1] - b0;
-    if (nb > FEA_CHUNK_BLOCKS) {                               // one long row in a chunk of its own: see spmv_body
-      double a0 = 0, a1 = 0, a2 = 0;
-      for (int k = lane; k < nb; k += 64) {
-        const int col = colidx[b0 + k];
-        const TK *vp = K + (size_t)(b0 + k) * 9;
-        const double x0 = xin[(size_t)col * 3], x1 = xin[(size_t)col * 3 + 1], x2 = xin[(size_t)col * 3 + 2];
-        a0 += (double)vp[0] * x0 + (double)vp[1] * x1 + (double)vp[2] * x2;
-        a1 += (double)vp[3] * x0 + (double)vp[4] * x1 + (double)vp[5] * x2;
-        a2 += (double)vp[6] * x0 + (double)vp[7] * x1 + (double)vp[8] * x2;
-      }
-      a0 = wave_sum_all(a0); a1 = wave_sum_all(a1); a2 = wave_sum_all(a2);
-      if (lane < 3) {
-        const double *rr = r + (size_t)r0 * 3;
-        const double t0 = rr[0] - a0, t1 = rr[1] - a1, t2 = rr[2] - a2;
-        const double *m = minv + (size_t)r0 * 9 + 3 * lane;
-        xout[(size_t)r0 * 3 + lane] = xin[(size_t)r0 * 3 + lane] + omega * (m[0] * t0 + m[1] * t1 + m[2] * t2);
-      }
-      continue;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int k = lane + 64 * h;
-      if (k < nb) {
-        const int kk = b0 + k;
-        const int col = colidx[kk];
-        const TK *vp = K + (size_t)kk * 9;
-        const double x0 = xin[(size_t)col * 3], x1 = xin[(size_t)col * 3 + 1], x2 = xin[(size_t)col * 3 + 2];
-        tP[k * 3 + 0] = (double)vp[0] * x0 + (double)vp[1] * x1 + (double)vp[2] * x2;
-        tP[k * 3 + 1] = (double)vp[3] * x0 + (double)vp[4] * x1 + (double)vp[5] * x2;
-        tP[k * 3 + 2] = (double)vp[6] * x0 + (double)vp[7] * x1 + (double)vp[8] * x2;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    const int t = lane, nt = (r1 - r0) * 3;              // <= 48: one pass
-    double res = 0.0;
-    const int row = r0 + t / 3, i = t % 3;
-    if (t < nt) {
-      const int kb = rowptr[row] - b0, ke = rowptr[row + 1] - b0;
-      double acc = 0;
-      for (int k = kb; k < ke; ++k) acc += tP[k * 3 + i];
-      res = r[(size_t)r0 * 3 + t] - acc;
-    }
-    const double t0 = __shfl(res, lane - i), t1 = __shfl(res, lane - i + 1), t2 = __shfl(res, lane - i + 2);
-    if (t < nt) {
-      const double *m = minv + (size_t)row * 9;
-      xout[(size_t)r0 * 3 + t] = xin[(size_t)r0 * 3 + t] + omega * (m[3 * i] * t0 + m[3 * i + 1] * t1 + m[3 * i + 2] * t2);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-  }
+  spmv_body<TK, true>(chunk0, nchunks, chunk, rowptr, colidx, K, xin, xout, part ? r : (const double *)nullptr, part,
+                      (const int *)nullptr, SpmvJacobi{r, minv, omega});
 }
 
-void enq_spmv_jacobi(hipStream_t stream, int nchunks, const int *chunk, const int *rowptr, const int *colidx, const double *K,
-                     const float *K32, const double *xin, double *xout, const double *r, const double *minv, double omega)
+// exactly one of K (double), K32 (float), K16 (bfloat16 rows of four) is given
+void enq_spmv_jacobi(hipStream_t stream, int chunk0, int nchunks, const int *chunk, const int *rowptr, const int *colidx, const double *K,
+                     const float *K32, const unsigned short *K16, const double *xin, double *xout, const double *r, const double *minv,
+                     double omega, double *part)
 {
   int g = (nchunks + FEA_WAVES_PER_WG - 1) / FEA_WAVES_PER_WG;
   g = g < FEA_RED_BLOCKS ? (g > 0 ? g : 1) : FEA_RED_BLOCKS;
-  if (K32) hipLaunchKernelGGL(k_spmv_jacobi<float>, dim3(g), dim3(256), 0, stream, nchunks, chunk, rowptr, colidx, K32, xin, xout, r, minv, omega);
-  else hipLaunchKernelGGL(k_spmv_jacobi<double>, dim3(g), dim3(256), 0, stream, nchunks, chunk, rowptr, colidx, K, xin, xout, r, minv, omega);
+#define SJ(TK, ptr) hipLaunchKernelGGL(k_spmv_jacobi<TK>, dim3(g), dim3(256), 0, stream, chunk0, nchunks, chunk, rowptr, colidx, ptr, xin, xout, r, minv, omega, part)
+  if (K16) SJ(bf16_t, reinterpret_cast<const bf16_t *>(K16));
+  else if (K32) SJ(float, K32);
+  else SJ(double, K);
+#undef SJ
 }
 
 static int spmv_grid(const feahip_ctx *c)
