@@ -111,7 +111,7 @@ struct feahip_ctx {
   // the same for 10-node tetrahedra (kernels_gather10.hip); shares d_gmaps / ngchunks / gather_row0.. with the above
   struct Gather10Layout *gather10_lay = nullptr;
   int *d_g10_elist = nullptr;            // this rank's elements
-  double *d_g10_state = nullptr;         // [elements of the rank][G][18]: Gauss-point state records (kernels_gather10.hip)
+  double *d_g10_state = nullptr;         // [G][elements of the rank][18]: Gauss-point state records (kernels_gather10.hip)
   int g10_nloc = 0;
   // vectors (3N doubles)
   double *d_f = nullptr, *d_u = nullptr;

@@ -32,6 +32,13 @@
 #define T_GMAX 32                     // Gauss points of a rule at most
 #define T_GLDS 8                      // rules up to this many points keep their shape-gradient table in LDS
 
+// record (element le, Gauss point g) of a rank with nloc elements: state[g][le][18], so that the 64 records a wave of
+// k_state10 produces per Gauss point are 9 216 contiguous bytes (and the records an expand wave reads are neighbours)
+__device__ __forceinline__ size_t t_state_index(int le, int g, int nloc)
+{
+  return ((size_t)g * nloc + le) * T_HDR;
+}
+
 struct S10Args {
   int nloc, G, model, row0, row1;
   double lambda, mu;
@@ -53,8 +60,10 @@ void k_state10(S10Args A)
   for (int i = threadIdx.x; i < A.G; i += 256) sTw[i] = A.tab->w[i];
   for (int i = threadIdx.x; i < A.G * 3 * NPE; i += 256) sTd[i] = A.tab->dN[i / (3 * NPE)][(i / NPE) % 3][i % NPE];
   __syncthreads();
-  const int le = blockIdx.x * 256 + threadIdx.x;
-  if (le >= A.nloc) return;
+  __shared__ __attribute__((aligned(16))) double sOut[4][64 * T_HDR];       // a wave's records of one Gauss point
+  const int le_raw = blockIdx.x * 256 + threadIdx.x;
+  const bool act = le_raw < A.nloc;
+  const int le = act ? le_raw : A.nloc - 1;                                 // the last wave: spare lanes repeat the last element, write nothing
   const int e = A.elist[le];
   const int *cn = A.conn + (size_t)e * NPE;
   double xc[NPE][3], Xc[NPE][3];
@@ -91,7 +100,7 @@ void k_state10(S10Args A)
     fd_inv3(Fi, F, detFi);
     double sig[3][3], l1, m1;
     fd_constitutive(F, A.model, A.lambda, A.mu, sig, l1, m1);
-    nbad += !(detJ > 0.0);
+    nbad += act && !(detJ > 0.0);
     double st[T_HDR];
 #pragma unroll
     for (int i = 0; i < T_HDR; ++i) st[i] = 0.0;
@@ -105,9 +114,22 @@ void k_state10(S10Args A)
       st[12] = vol * sig[1][1]; st[13] = vol * sig[1][2]; st[14] = vol * sig[2][2];
       st[15] = vol * l1; st[16] = vol * m1;
     }
-    double2 *o = reinterpret_cast<double2 *>(A.state + ((size_t)le * A.G + g) * T_HDR);
+    {
+      // a lane storing its own 144-byte record touches a cache line of its own with every store instruction (64 lines
+      // per instruction, nine instructions per point); through LDS the wave writes 1 KB per instruction
+      const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      double2 *so = reinterpret_cast<double2 *>(sOut[wave] + lane * T_HDR);
 #pragma unroll
-    for (int i = 0; i < T_HDR / 2; ++i) o[i] = make_double2(st[2 * i], st[2 * i + 1]);
+      for (int i = 0; i < T_HDR / 2; ++i) so[i] = make_double2(st[2 * i], st[2 * i + 1]);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      const int le0 = blockIdx.x * 256 + wave * 64;
+      const int np = (A.nloc - le0 < 64 ? A.nloc - le0 : 64) * (T_HDR / 2);
+      double2 *o = reinterpret_cast<double2 *>(A.state + t_state_index(le0, g, A.nloc));
+      const double2 *si = reinterpret_cast<const double2 *>(sOut[wave]);
+#pragma unroll
+      for (int j = 0; j < T_HDR / 2; ++j) { const int p = lane + 64 * j; if (p < np) o[p] = si[p]; }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
   }
   if (A.bad && mine && nbad) atomicAdd(A.bad, nbad);
 }
@@ -118,6 +140,7 @@ struct G10Args {
   const unsigned char *maps;
   Gather10Layout lay;
   const double *state;
+  int nloc;                     // elements of the rank (state records per Gauss point)
   double *K, *f;
   unsigned long long *stamps;   // diagnostic build only
 };
@@ -260,8 +283,9 @@ void k_assemble_gather10(G10Args A, int run_len)
     const int parts = 4 * nelem <= FEA_Q_THREADS ? 4 : (3 * nelem <= FEA_Q_THREADS ? 3 : 2);
     const int xe = parts == 4 ? t >> 2 : (parts == 3 ? (int)(((unsigned)t * 21846u) >> 16) : t >> 1), xp = t - xe * parts;
     const bool xact = xe < nelem;
-    const double2 *srec = reinterpret_cast<const double2 *>(
-        A.state + (size_t)reinterpret_cast<const uint32_t *>(rec + A.lay.o_elems)[xact ? xe : 0] * G * T_HDR);
+    const int xle = (int)reinterpret_cast<const uint32_t *>(rec + A.lay.o_elems)[xact ? xe : 0];
+    const double2 *srec = reinterpret_cast<const double2 *>(A.state + t_state_index(xle, 0, A.nloc));
+    const size_t gstride = (size_t)A.nloc * (T_HDR / 2);   // double2 between the Gauss points of an element
     if (t < FEA_Q_ROWS_U16 / 2) reinterpret_cast<uint32_t *>(sRows)[t] = reinterpret_cast<const uint32_t *>(rec + A.lay.o_rows)[t];
     uint32_t tp[FEA_Q_SLOTS], cw[FEA_Q_SLOTS][FEA_Q_REGW], fw[FEA_Q_REGW];
     const uint32_t *cl = reinterpret_cast<const uint32_t *>(rec + A.lay.o_clist) + t;
@@ -326,7 +350,7 @@ void k_assemble_gather10(G10Args A, int run_len)
         }
       }
       {                                                  // the next Gauss point's record: in flight under the gather
-        const double2 *nx = srec + (size_t)(g + 1 < G ? g + 1 : g) * (T_HDR / 2);
+        const double2 *nx = srec + (size_t)(g + 1 < G ? g + 1 : g) * gstride;
 #pragma unroll
         for (int i = 0; i < T_HDR / 2; ++i) hn[i] = nx[i];
       }
@@ -502,7 +526,7 @@ int launch_assemble_gather10(feahip_ctx *c, bool doK, bool doF)
   }
   G10Args A;
   A.nchunks = c->ngchunks; A.G = c->G; A.tab = c->d_table; A.maps = c->d_gmaps; A.lay = *c->gather10_lay;
-  A.state = c->d_g10_state; A.K = c->d_K; A.f = c->d_f; A.stamps = nullptr;
+  A.state = c->d_g10_state; A.nloc = c->g10_nloc; A.K = c->d_K; A.f = c->d_f; A.stamps = nullptr;
 #ifdef FEAHIP_DEBUG
   static unsigned long long *d_stamps = nullptr;
   static int cap = 0;
