@@ -188,6 +188,9 @@ struct bf16_t { unsigned short v[4]; };
 #define FEA_SPMV_STAGED 1      // bit 0: double matrices, 1: float, 2: bfloat16 (measured: only the 72-byte blocks gain)
 #endif
 typedef double spmv_v2d __attribute__((ext_vector_type(2)));
+#ifndef FEA_VEC_BY_DOF
+#define FEA_VEC_BY_DOF 1
+#endif
 #ifndef SPMV_HOIST
 #define SPMV_HOIST 1
 #endif
@@ -569,6 +572,28 @@ void k_cg_update(int a0, int a1, int it, int n_pq, const double *p, const double
   const double rz = scal[it & 1];
   const double alpha = rz / pq;
   double srz = 0, srr = 0;
+#if FEA_VEC_BY_DOF
+  // lane <-> scalar dof, 21 nodes per wave and step: every vector is read as one contiguous run per instruction, and
+  // so is D^-1 (row i of node a's block is the three doubles at 3 (3a + i)); the three residual components of a node
+  // meet by shuffles.  (A lane per node read its nine inverse values with a 72-byte stride between lanes.)
+  const int lane = threadIdx.x & 63, i = lane % 3;
+  const bool lane_on = lane < 63;
+  for (long long nb = a0 + (long long)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 21; nb < a1; nb += (long long)gridDim.x * 4 * 21) {
+    const long long a = nb + lane / 3;
+    const bool on = lane_on && a < a1;
+    const size_t k = (size_t)nb * 3 + lane;
+    double rv = 0;
+    if (on) { x[k] += alpha * p[k]; rv = r[k] - alpha * q[k]; r[k] = rv; }
+    double z = rv;
+    if (minv) {
+      double m0 = 0, m1 = 0, m2 = 0;
+      if (on) { const double *m = minv + 3 * k; m0 = m[0]; m1 = m[1]; m2 = m[2]; }
+      const double r0 = __shfl(rv, lane - i), r1 = __shfl(rv, lane - i + 1), r2 = __shfl(rv, lane - i + 2);
+      z = m0 * r0 + m1 * r1 + m2 * r2;
+    }
+    if (on) { srz += rv * z; srr += rv * rv; if (zq) zq[k] = z; }
+  }
+#else
   for (int a = a0 + blockIdx.x * 256 + threadIdx.x; a < a1; a += gridDim.x * 256) {
     const double *m = minv + (size_t)a * 9;
     double rv[3];
@@ -584,6 +609,7 @@ void k_cg_update(int a0, int a1, int it, int n_pq, const double *p, const double
       if (zq) zq[(size_t)a * 3 + i] = z;
     }
   }
+#endif
   srz = block_sum(srz, scratch); srr = block_sum(srr, scratch);
   if (threadIdx.x == 0) { part[RB + blockIdx.x] = srz; part[2 * RB + blockIdx.x] = srr; }
 }
@@ -603,6 +629,10 @@ void k_cg_direction(int a0, int a1, int it, int nparts, const double *r, const d
   const bool broke = !(rz_new == rz_new) || !(rr == rr) || rz_old == 0.0;
   if (!stop && !broke) {
     const double beta = rz_new / rz_old;
+    if (FEA_VEC_BY_DOF && !minv) {                      // z is given: one contiguous run per instruction
+      for (size_t k = (size_t)a0 * 3 + blockIdx.x * 256 + threadIdx.x; k < (size_t)a1 * 3; k += (size_t)gridDim.x * 256)
+        p[k] = r[k] + beta * p[k];
+    } else
     for (int a = a0 + blockIdx.x * 256 + threadIdx.x; a < a1; a += gridDim.x * 256) {
       const double *m = minv + (size_t)a * 9;
       const double r0 = r[(size_t)a * 3], r1 = r[(size_t)a * 3 + 1], r2 = r[(size_t)a * 3 + 2];
@@ -652,6 +682,32 @@ void k_cgcg_update(int a0, int a1, int it, const double *z, const double *w, con
     broke = !(alpha == alpha) || !(beta == beta) || alpha == 0.0;
   }
   double sg = 0, srr = 0;
+#if FEA_VEC_BY_DOF
+  if (!stop && !broke) {                                // lane <-> scalar dof, 21 nodes per wave and step (k_cg_update)
+    const int lane = threadIdx.x & 63, i = lane % 3;
+    const bool lane_on = lane < 63;
+    for (long long nb = a0 + (long long)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 21; nb < a1; nb += (long long)gridDim.x * 4 * 21) {
+      const bool on = lane_on && nb + lane / 3 < a1;
+      const size_t k = (size_t)nb * 3 + lane;
+      double rv = 0;
+      if (on) {
+        const double pk = z[k] + beta * p[k], sk = w[k] + beta * s[k];
+        p[k] = pk; s[k] = sk;
+        x[k] += alpha * pk;
+        rv = r[k] - alpha * sk;
+        r[k] = rv;
+      }
+      srr += rv * rv;
+      if (minv) {                                       // block-Jacobi: z = M r here; multigrid: the cycle follows
+        double m0 = 0, m1 = 0, m2 = 0;
+        if (on) { const double *m = minv + 3 * k; m0 = m[0]; m1 = m[1]; m2 = m[2]; }
+        const double r0 = __shfl(rv, lane - i), r1 = __shfl(rv, lane - i + 1), r2 = __shfl(rv, lane - i + 2);
+        const double zz = m0 * r0 + m1 * r1 + m2 * r2;
+        if (on) { znew[k] = zz; sg += rv * zz; }
+      }
+    }
+  }
+#else
   if (!stop && !broke) {
     for (int a = a0 + blockIdx.x * 256 + threadIdx.x; a < a1; a += gridDim.x * 256) {
       const double *m = minv + (size_t)a * 9;
@@ -674,6 +730,7 @@ void k_cgcg_update(int a0, int a1, int it, const double *z, const double *w, con
       }
     }
   }
+#endif
   sg = block_sum(sg, scratch); srr = block_sum(srr, scratch);
   if (threadIdx.x == 0) { part[RB + blockIdx.x] = sg; part[2 * RB + blockIdx.x] = srr; }
   // the scalars of this iteration go to the other ping-pong slots; the flag is read at kernel entry only

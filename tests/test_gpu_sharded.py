@@ -227,6 +227,7 @@ def test_rccl_single_rank_comm():
     ref = feahip.FeaSolver(deck)
     ref.update_nodes_with_bc(1.0); ref.create_stiffness_and_residual(); ref.apply_prescribed_bc(0.0)
     it2, _ = ref.solve_slae(feahip.PCG_ILU, 1e-14, 5000)
-    assert it == it2 and rel(s.solution(), ref.solution()) < 1e-13
+    # (the communicator selects the single-reduction recurrence: same iterates in exact arithmetic, counts within 2)
+    assert abs(it - it2) <= 2 and rel(s.solution(), ref.solution()) < 1e-13
     assert s.energy() == pytest.approx(ref.energy(), rel=1e-13)
     s.close(); ref.close()
