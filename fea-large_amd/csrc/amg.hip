@@ -248,8 +248,9 @@ __global__ void k_to_f32(size_t n, const double *src, float *dst)
 {
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) dst[t] = (float)src[t];
 }
-// (n rows of three values -> rows of four: three values and a zero pad, 8 bytes)
-__global__ void k_to_bf16(size_t nrows3, const double *src, unsigned short *dst)
+// (n rows of three values -> rows of four, 8 bytes: three values and a pad.  The pads of a block's first two rows carry
+// the low and the high half of its column index: the smoother's product reads 24 bytes per block and no index array)
+__global__ void k_to_bf16(size_t nrows3, const double *src, const int *col, unsigned short *dst)
 {
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nrows3; t += (size_t)gridDim.x * blockDim.x) {
     unsigned short o[4] = {0, 0, 0, 0};
@@ -257,7 +258,10 @@ __global__ void k_to_bf16(size_t nrows3, const double *src, unsigned short *dst)
       const unsigned u = __float_as_uint((float)src[t * 3 + j]);
       o[j] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
     }
-    reinterpret_cast<uint2 *>(dst)[t] = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2]);
+    const unsigned c = (unsigned)col[t / 3];
+    const int rib = (int)(t % 3);
+    o[3] = rib == 0 ? (unsigned short)(c & 0xFFFFu) : (rib == 1 ? (unsigned short)(c >> 16) : (unsigned short)0);
+    reinterpret_cast<uint2 *>(dst)[t] = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
   }
 }
 
@@ -675,7 +679,7 @@ static int amg_numeric(feahip_ctx *c)
     const LevelRange R = level_range(c, l);
     if (l == 0 && (L.K32 || L.K16)) {                    // the rank's rows only
       const size_t q0 = (size_t)c->h_rowptr[(size_t)h->row0] * 9, q1 = (size_t)c->h_rowptr[(size_t)h->row1] * 9;
-      if (L.K16) hipLaunchKernelGGL(k_to_bf16, dim3(4096), dim3(256), 0, c->stream, (q1 - q0) / 3, (const double *)L.K + q0, L.K16 + q0 / 3 * 4);
+      if (L.K16) hipLaunchKernelGGL(k_to_bf16, dim3(4096), dim3(256), 0, c->stream, (q1 - q0) / 3, (const double *)L.K + q0, L.colidx + q0 / 9, L.K16 + q0 / 3 * 4);
       else hipLaunchKernelGGL(k_to_f32, dim3(4096), dim3(256), 0, c->stream, q1 - q0, (const double *)L.K + q0, L.K32 + q0);
     }
     if (l > 0 && L.K32) hipLaunchKernelGGL(k_block_inverse<float>, GROWS(R), R.a0, R.a1, L.diag, L.K32, L.minv);

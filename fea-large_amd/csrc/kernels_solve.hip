@@ -213,6 +213,28 @@ __device__ __forceinline__ void load_block9<bf16_t>(const bf16_t *K, size_t kk, 
     v[3 * i + 2] = (double)__uint_as_float(w.y << 16);
   }
 }
+// nine values and the column index of block kk.  bf16_t blocks carry their index in the pads of rows 0 and 1
+// (k_to_bf16, amg.hip): no index load
+template <class TK>
+__device__ __forceinline__ int load_block9_col(const TK *K, const int *colidx, size_t kk, double (&v)[9])
+{
+  load_block9<TK>(K, kk, v);
+  return colidx[kk];
+}
+template <>
+__device__ __forceinline__ int load_block9_col<bf16_t>(const bf16_t *K, const int *, size_t kk, double (&v)[9])
+{
+  const uint2 *vp = reinterpret_cast<const uint2 *>(K) + kk * 3;
+  uint2 w[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    w[i] = vp[i];
+    v[3 * i] = (double)__uint_as_float(w[i].x << 16);
+    v[3 * i + 1] = (double)__uint_as_float(w[i].x & 0xFFFF0000u);
+    v[3 * i + 2] = (double)__uint_as_float(w[i].y << 16);
+  }
+  return (int)((w[0].y >> 16) | (w[1].y & 0xFFFF0000u));
+}
 // JAC: y = x + omega D^-1 (r - K x) instead of y = K x (one damped block-Jacobi sweep fused with its product: the rows of
 // a chunk -- at most FEA_CHUNK_ROWS = 16, i.e. 48 lanes -- exchange their three residual components by shuffles and apply
 // the inverse diagonal block; y must not be x).  dotwith / part: partial sums of y . dotwith in either mode.
@@ -243,9 +265,8 @@ __device__ __forceinline__ void spmv_body(int chunk0, int nchunks, const int *ch
       // (the reference's solvers have no row-length limit either, fea_solver.c:300-321)
       double a0 = 0, a1 = 0, a2 = 0;
       for (int k = lane; k < nb; k += 64) {
-        const int col = colidx[b0 + k];
         double vp[9];
-        load_block9<TK>(K, (size_t)(b0 + k), vp);
+        const int col = load_block9_col<TK>(K, colidx, (size_t)(b0 + k), vp);
         const double x0 = x[(size_t)col * 3], x1 = x[(size_t)col * 3 + 1], x2 = x[(size_t)col * 3 + 2];
         a0 += vp[0] * x0 + vp[1] * x1 + vp[2] * x2;
         a1 += vp[3] * x0 + vp[4] * x1 + vp[5] * x2;
@@ -329,8 +350,7 @@ __device__ __forceinline__ void spmv_body(int chunk0, int nchunks, const int *ch
       const int k = lane + 64 * h;
       const bool on = k < nb;
       const int kk = on ? b0 + k : b0;
-      const int col = colidx[kk];
-      load_block9<TK>(K, (size_t)kk, v[h]);
+      const int col = load_block9_col<TK>(K, colidx, (size_t)kk, v[h]);
 #pragma unroll
       for (int i = 0; i < 3; ++i) xv[h][i] = x[(size_t)col * 3 + i];
     }
