@@ -50,6 +50,7 @@ struct AmgHierarchy {
   int coarse_sweeps = 2;                 // damped Jacobi sweeps on the coarsest level (amg_setup.cpp: why so few)
   int tail_from = -1;                    // first level of the subtree the one-workgroup kernel runs (amg.hip: k_amg_tail); -1: none
   int gamma_from = 0;                    // first level whose coarse correction is repeated `gamma` times
+  int gamma_until = 1 << 20;             // ... and the first level below them that runs a single correction again (FEAHIP_AMG_GAMMA_UNTIL)
   int gamma = 2;                         // coarse corrections per level below the finest (2 = W-cycle)
   double over = 2.0;                     // over-correction of the prolongated correction (<= 2 keeps the cycle SPD);
                                          // 10M-tet block, PCG to 1e-14: V-cycle 274 iterations (over 1.5), W-cycle below the

@@ -567,6 +567,7 @@ int amg_create(feahip_ctx *c)
   { const char *e = getenv("FEAHIP_AMG_FINE_BITS"); if (e && (atoi(e) == 32 || atoi(e) == 64)) h->fine_bits = atoi(e); }
   { const char *e = getenv("FEAHIP_AMG_OVER"); if (e) h->over = atof(e); }
   { const char *e = getenv("FEAHIP_AMG_GAMMA_FROM"); if (e) h->gamma_from = atoi(e); }
+  { const char *e = getenv("FEAHIP_AMG_GAMMA_UNTIL"); if (e) h->gamma_until = atoi(e); }
   { const char *e = getenv("FEAHIP_AMG_FUSED_POST"); h->fused_post = e && atoi(e) != 0; }
   { const char *e = getenv("FEAHIP_AMG_SWEEPS"); if (e) h->coarse_sweeps = atoi(e); }
   // the levels the one-workgroup kernel takes: from the first level below the finest of at most FEA_TAIL_ROWS rows
@@ -744,7 +745,7 @@ static void launch_tail(feahip_ctx *c)
     T.o_v = off; off += 9 * L.N;
     T.o_aux = off; off += T_AUX_DOUBLES(L.N, L.Nc / 2);
     T.o_K = -1;
-    A.gamma[k] = (l < h->gamma_from) ? 1 : h->gamma;
+    A.gamma[k] = (l < h->gamma_from || l >= h->gamma_until) ? 1 : h->gamma;
     A.over[k] = A.gamma[k] >= 2 ? h->over : fmin(h->over, 1.0);
   }
   for (int k = nl - 1; k >= 0; --k) {                   // small matrices too, the most visited first, while they fit
@@ -784,7 +785,7 @@ static double *amg_cycle(feahip_ctx *c, int l, const double *r, double *x, doubl
     return x;
   }
   AmgLevel &C = h->lv[l + 1];
-  const int gamma = (l < h->gamma_from) ? 1 : h->gamma;
+  const int gamma = (l < h->gamma_from || l >= h->gamma_until) ? 1 : h->gamma;
   for (int g = 0; g < gamma; ++g) {
     level_spmv(c, L, R, x, y);
     hipLaunchKernelGGL(k_restrict, G256((C.N / 2) * 16), C.N / 2, L.aptr, L.anodes, L.type, L.doff, r, y, mask, C.r);
