@@ -599,8 +599,13 @@ def main():
             dist.destroy_process_group()
         except Exception:                           # noqa: BLE001
             pass
+    # The assembly line above is complete and measured even when the solve leg behind it failed: the failure is in the
+    # line (extras.rccl_sharded_solve / extras.solve_leg) and on stderr; it becomes the exit code only on request, so that
+    # a scaling run keeps its assembly numbers.
     if rc_exit:
-        sys.exit(rc_exit)
+        print(f"[rank {rank}] solve leg failed (code {rc_exit}): {extras.get('solve_leg')}", file=sys.stderr)
+        if os.environ.get("FEAHIP_BENCH_STRICT", "0") == "1":
+            sys.exit(rc_exit)
 
 
 if __name__ == "__main__":
