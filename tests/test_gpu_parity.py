@@ -239,7 +239,7 @@ def test_multigrid_preconditioner_same_solution_fewer_iterations():
 def test_multigrid_variants_are_the_same_preconditioner(monkeypatch):
     """The measurement knobs of the cycle change how it is computed, not what: the small levels in one launch
     (k_amg_tail) or kernel by kernel, the post-smoothing sweep fused with its product or in two launches, the smoother's
-    level-0 matrix in bfloat16 / float / double, a shallower hierarchy.
+    level-0 matrix in bfloat16 / float / double, a shallower hierarchy, single corrections below the finest level.
     Every variant must solve the same system to the same answer; the one-launch tail repeats the kernel-by-kernel
     iteration count exactly (same steps, same order), the matrix precision may move it by a few iterations."""
     deck = mesh.bar_deck(dims=(8, 48, 8))
@@ -251,9 +251,11 @@ def test_multigrid_variants_are_the_same_preconditioner(monkeypatch):
     s.close()
     its = {}
     for name, env in (("default", {}), ("no_tail", {"FEAHIP_AMG_TAIL": "0"}), ("fused_post", {"FEAHIP_AMG_FUSED_POST": "1"}),
+                      ("v_below_1", {"FEAHIP_AMG_GAMMA_UNTIL": "1"}),
                       ("f32", {"FEAHIP_AMG_FINE_BITS": "32"}),
                       ("f64", {"FEAHIP_AMG_FINE_BITS": "64"}), ("shallow", {"FEAHIP_AMG_COARSEST": "1500", "FEAHIP_AMG_SWEEPS": "12"})):
-        for k in ("FEAHIP_AMG_TAIL", "FEAHIP_AMG_FINE_BITS", "FEAHIP_AMG_COARSEST", "FEAHIP_AMG_SWEEPS", "FEAHIP_AMG_FUSED_POST"):
+        for k in ("FEAHIP_AMG_TAIL", "FEAHIP_AMG_FINE_BITS", "FEAHIP_AMG_COARSEST", "FEAHIP_AMG_SWEEPS", "FEAHIP_AMG_FUSED_POST",
+                  "FEAHIP_AMG_GAMMA_UNTIL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
