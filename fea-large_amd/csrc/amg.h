@@ -66,6 +66,8 @@ struct AmgHierarchy {
   int row0 = 0, row1 = 0;                // rows of level 0 this hierarchy covers (the rank's own)
   double *d_z = nullptr;                 // level-0 iterate of the cycle (zero outside the rank's rows)
   double *result = nullptr;              // where the last cycle left z: d_z, or the context's q when the last sweep is fused
+  double *d_tail_blob = nullptr;         // the tail levels' read-only arrays in the tail kernel's LDS layout, repacked at every numeric setup
+  bool tail_blob = true;                 // (FEAHIP_AMG_TAIL_BLOB=0: every launch gathers them array by array)
   bool fused_post = false;               // post-smoothing product and update in one launch (FEAHIP_AMG_FUSED_POST=1; measured 1.6-2.5 % slower per CG iteration than the two launches)
   double *d_pw = nullptr;                // scratch for the power iteration
   long long bytes = 0;

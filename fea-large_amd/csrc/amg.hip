@@ -334,7 +334,18 @@ struct TailArgs {
   TailLevel lv[FEA_TAIL_MAXL];
   int gamma[FEA_TAIL_MAXL]; double over[FEA_TAIL_MAXL];
   int nl, sweeps;
+  unsigned long long *stamps;            // diagnostic build only: [level][8] accumulated s_memtime ticks per phase kind, [32] launches
+  const double *blob;                    // the levels' read-only arrays and small matrices in their LDS layout (k_tail_pack), or null
+  int blob_lo, blob_n;                   // LDS doubles [blob_lo, blob_lo + blob_n): one contiguous copy per launch
+  int lds_doubles;                       // all of it
 };
+#ifdef FEAHIP_DEBUG
+__device__ unsigned long long g_tail_prev;
+#define TS(l, cat) do { if (A.stamps && threadIdx.x == 0) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+                          atomicAdd(A.stamps + (l) * 8 + (cat), _t - g_tail_prev); g_tail_prev = _t; } } while (0)
+#else
+#define TS(l, cat) do { } while (0)
+#endif
 #define T_R(L) (smem + (L).o_v)
 #define T_X(L) (smem + (L).o_v + 3 * (L).N)
 #define T_Y(L) (smem + (L).o_v + 6 * (L).N)
@@ -469,29 +480,43 @@ template <int D>
 __device__ void t_cycle(const TailArgs &A, int l, double *smem)
 {
   const TailLevel &L = A.lv[l];
+  if ((L.Nc == 0 || D == 0) && L.N <= 16) {
+    // a coarsest level of at most 16 block rows (10 on the 10M-tet block, visited 16 times per cycle) is the work of
+    // one wave: its 1 + 2 * sweeps steps follow each other in program order (a wave's LDS operations complete in
+    // order), the other fifteen waves wait at ONE barrier instead of taking part in five
+    if (threadIdx.x < 64) {
+      t_smooth_first(L, smem);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      for (int s = 0; s < A.sweeps; ++s) {
+        t_spmv(L, smem); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        t_smooth_next(L, smem); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      }
+    }
+    __syncthreads(); TS(l, 1);
+    return;
+  }
   t_smooth_first(L, smem);
-  __syncthreads();
+  __syncthreads(); TS(l, 1);
   if (L.Nc == 0 || D == 0) {                            // the coarsest level: a few damped Jacobi sweeps
-    for (int s = 0; s < A.sweeps; ++s) { t_spmv(L, smem); __syncthreads(); t_smooth_next(L, smem); __syncthreads(); }
+    for (int s = 0; s < A.sweeps; ++s) { t_spmv(L, smem); __syncthreads(); TS(l, 2); t_smooth_next(L, smem); __syncthreads(); TS(l, 1); }
     return;
   }
   for (int g = 0; g < A.gamma[l]; ++g) {
-    t_spmv(L, smem); __syncthreads();
-    t_restrict(L, A.lv[l + 1], smem); __syncthreads();
+    t_spmv(L, smem); __syncthreads(); TS(l, 2);
+    t_restrict(L, A.lv[l + 1], smem); __syncthreads(); TS(l, 3);
     if (D > 0) t_cycle<(D > 0 ? D - 1 : 0)>(A, l + 1, smem);
-    t_prolong(L, A.lv[l + 1], A.over[l], smem); __syncthreads();
+    t_prolong(L, A.lv[l + 1], A.over[l], smem); __syncthreads(); TS(l, 4);
   }
-  t_spmv(L, smem); __syncthreads();
-  t_smooth_next(L, smem); __syncthreads();
+  t_spmv(L, smem); __syncthreads(); TS(l, 2);
+  t_smooth_next(L, smem); __syncthreads(); TS(l, 1);
 }
-__global__ __launch_bounds__(FEA_TAIL_T)
-void k_amg_tail(TailArgs A)
+// the levels' read-only arrays and the small matrices, laid out as the kernel's LDS holds them, written to `base`
+// (k_amg_tail without a blob: its LDS; k_tail_pack: the global blob the launches then copy in one go)
+__device__ __forceinline__ void t_stage(const TailArgs &A, double *base)
 {
-  extern __shared__ __attribute__((aligned(16))) double tail_smem[];
-  double *smem = tail_smem;
-  for (int l = 0; l < A.nl; ++l) {                      // the levels' read-only arrays into LDS
+  for (int l = 0; l < A.nl; ++l) {
     const TailLevel &L = A.lv[l];
-    double *minv = smem + L.o_aux, *doff = minv + 9 * L.N;
+    double *minv = base + L.o_aux, *doff = minv + 9 * L.N;
     int *rowptr = reinterpret_cast<int *>(doff + 3 * L.N), *agg = rowptr + L.N + 1, *type = agg + L.N, *anodes = type + L.N,
         *aptr = anodes + L.N;
     for (int i = threadIdx.x; i < 9 * L.N; i += FEA_TAIL_T) minv[i] = L.minv[i];
@@ -505,29 +530,53 @@ void k_amg_tail(TailArgs A)
   for (int l = 0; l < A.nl; ++l) {                      // small matrices too
     const TailLevel &L = A.lv[l];
     if (L.o_K < 0) continue;
-    float *sK = reinterpret_cast<float *>(smem + L.o_K);
+    float *sK = reinterpret_cast<float *>(base + L.o_K);
     int *sCol = reinterpret_cast<int *>(sK + (size_t)L.nnzb * 9);
     for (int i = threadIdx.x; i < L.nnzb * 9; i += FEA_TAIL_T) sK[i] = L.K32[i];
     for (int i = threadIdx.x; i < L.nnzb; i += FEA_TAIL_T) sCol[i] = L.colidx[i];
   }
+}
+__global__ __launch_bounds__(FEA_TAIL_T)
+void k_tail_pack(TailArgs A, double *blob)
+{
+  t_stage(A, blob - A.blob_lo);
+}
+__global__ __launch_bounds__(FEA_TAIL_T)
+void k_amg_tail(TailArgs A)
+{
+  extern __shared__ __attribute__((aligned(16))) double tail_smem[];
+  double *smem = tail_smem;
+#ifdef FEAHIP_DEBUG
+  if (A.stamps && threadIdx.x == 0) { g_tail_prev = __builtin_amdgcn_s_memtime(); atomicAdd(A.stamps + 32, 1ull); }
+#endif
+  if (A.blob) {
+    // one contiguous copy, every load in flight before the first wait (the per-array loops paid one L2 round trip each:
+    // 3.9 us of a 33.6 us launch, 632 launches per solve of data that changes once per Newton iteration)
+    typedef double tl_v2d __attribute__((ext_vector_type(2)));
+    const tl_v2d *src = reinterpret_cast<const tl_v2d *>(A.blob);
+    tl_v2d *dst = reinterpret_cast<tl_v2d *>(smem + A.blob_lo);
+    for (int i = threadIdx.x; i < A.blob_n / 2; i += FEA_TAIL_T) dst[i] = src[i];
+  } else t_stage(A, smem);
   {
     const TailLevel &L = A.lv[0];
     double *r = T_R(L);
     for (int i = threadIdx.x; i < 3 * L.N; i += FEA_TAIL_T) r[i] = L.r[i];
   }
-  __syncthreads();
+  __syncthreads(); TS(0, 0);
   t_cycle<FEA_TAIL_MAXL - 1>(A, 0, smem);
   {
     const TailLevel &L = A.lv[0];
     const double *x = T_X(L);
     for (int i = threadIdx.x; i < 3 * L.N; i += FEA_TAIL_T) L.x[i] = x[i];
   }
+  TS(0, 5);
 }
 
 // ---------------------------------------------------------------------------
 // hierarchy
 // ---------------------------------------------------------------------------
 static AmgHierarchy *H(feahip_ctx *c) { return reinterpret_cast<AmgHierarchy *>(c->amg); }
+static TailArgs tail_args(feahip_ctx *c);
 
 template <class T>
 static int up(feahip_ctx *c, T **dst, const std::vector<T> &v, long long &bytes)
@@ -568,6 +617,7 @@ int amg_create(feahip_ctx *c)
   { const char *e = getenv("FEAHIP_AMG_OVER"); if (e) h->over = atof(e); }
   { const char *e = getenv("FEAHIP_AMG_GAMMA_FROM"); if (e) h->gamma_from = atoi(e); }
   { const char *e = getenv("FEAHIP_AMG_GAMMA_UNTIL"); if (e) h->gamma_until = atoi(e); }
+  { const char *e = getenv("FEAHIP_AMG_TAIL_BLOB"); h->tail_blob = !(e && atoi(e) == 0); }
   { const char *e = getenv("FEAHIP_AMG_FUSED_POST"); h->fused_post = e && atoi(e) != 0; }
   { const char *e = getenv("FEAHIP_AMG_SWEEPS"); if (e) h->coarse_sweeps = atoi(e); }
   // the levels the one-workgroup kernel takes: from the first level below the finest of at most FEA_TAIL_ROWS rows
@@ -629,6 +679,10 @@ int amg_create(feahip_ctx *c)
   }
   if ((rc = zeros(c, &h->d_z, (size_t)c->ndof, h->bytes))) return rc;
   if ((rc = zeros(c, &h->d_pw, (size_t)c->ndof, h->bytes))) return rc;
+  if (h->tail_from >= 0 && h->tail_blob) {
+    const TailArgs A = tail_args(c);
+    if ((rc = zeros(c, &h->d_tail_blob, (size_t)A.blob_n, h->bytes))) return rc;
+  }
   return FEAHIP_OK;
 }
 
@@ -644,6 +698,7 @@ void amg_destroy(feahip_ctx *c)
   }
   if (h->d_z) (void)hipFree(h->d_z);
   if (h->d_pw) (void)hipFree(h->d_pw);
+  if (h->d_tail_blob) (void)hipFree(h->d_tail_blob);
   delete h;
   c->amg = nullptr;
 }
@@ -715,6 +770,10 @@ static int amg_numeric(feahip_ctx *c)
     }
     L.omega = 4.0 / (3.0 * 1.1 * lam);        // 10 % margin: the power iteration approaches lambda_max from below
   }
+  if (h->d_tail_blob) {                                  // the tail's read-only arrays for this K, in its LDS layout
+    const TailArgs A = tail_args(c);
+    hipLaunchKernelGGL(k_tail_pack, dim3(1), dim3(FEA_TAIL_T), 0, c->stream, A, h->d_tail_blob);
+  }
   FEA_HIP_CHECK(c, hipGetLastError());
   h->numeric_valid = true;
   return FEAHIP_OK;
@@ -727,7 +786,9 @@ static int amg_numeric(feahip_ctx *c)
 // correction of plain aggregation is too small by a mesh-independent factor;
 // `over` scales it (over-correction).
 // the subtree from level tail_from down, in one launch: reads its r, leaves its x (what amg_cycle does for that level)
-static void launch_tail(feahip_ctx *c)
+// arguments and LDS layout of the tail: the vectors of all levels first, then -- contiguous, even offsets -- the
+// read-only arrays of all levels and the small matrices: that second part is what k_tail_pack writes to the blob
+static TailArgs tail_args(feahip_ctx *c)
 {
   AmgHierarchy *h = H(c);
   TailArgs A;
@@ -743,17 +804,48 @@ static void launch_tail(feahip_ctx *c)
     T.agg = L.agg; T.aptr = L.aptr; T.anodes = L.anodes; T.type = L.type; T.doff = L.doff;
     T.r = L.r; T.x = L.x;
     T.o_v = off; off += 9 * L.N;
-    T.o_aux = off; off += T_AUX_DOUBLES(L.N, L.Nc / 2);
     T.o_K = -1;
     A.gamma[k] = (l < h->gamma_from || l >= h->gamma_until) ? 1 : h->gamma;
     A.over[k] = A.gamma[k] >= 2 ? h->over : fmin(h->over, 1.0);
   }
+  off += off & 1;
+  A.blob_lo = off;
+  for (int k = 0; k < nl; ++k) { const AmgLevel &L = h->lv[h->tail_from + k]; A.lv[k].o_aux = off; off += T_AUX_DOUBLES(L.N, L.Nc / 2); }
   for (int k = nl - 1; k >= 0; --k) {                   // small matrices too, the most visited first, while they fit
     const AmgLevel &L = h->lv[h->tail_from + k];
     const int need = (L.nnzb * 10 + 1) / 2 + 1;
     if (L.K32 && L.nnzb <= FEA_TAIL_LDS_BLOCKS && (off + need) * 8 <= 150 * 1024) { A.lv[k].o_K = off; off += need; }
   }
+  off += off & 1;
+  A.blob_n = off - A.blob_lo;
+  A.lds_doubles = off;
   A.nl = nl; A.sweeps = h->coarse_sweeps;
+  A.blob = h->d_tail_blob;
+  return A;
+}
+
+static void launch_tail(feahip_ctx *c)
+{
+  TailArgs A = tail_args(c);
+  const int off = A.lds_doubles;
+  A.stamps = nullptr;
+#ifdef FEAHIP_DEBUG
+  static unsigned long long *d_stamps = nullptr;
+  if (getenv("FEAHIP_TAIL_STAMPS")) {
+    if (!d_stamps) { (void)hipMalloc((void **)&d_stamps, 8 * 40); (void)hipMemset(d_stamps, 0, 8 * 40); }
+    A.stamps = d_stamps;
+    static int calls = 0;
+    if (++calls % 2000 == 0) {
+      unsigned long long hs[40];
+      (void)hipMemcpy(hs, d_stamps, sizeof(hs), hipMemcpyDeviceToHost);
+      const double n = (double)(hs[32] ? hs[32] : 1);
+      const char *nm[6] = {"stage", "smooth", "spmv", "restrict", "prolong", "writeback"};
+      fprintf(stderr, "[tail stamps, ticks of s_memtime per launch over %.0f launches]", n);
+      for (int l = 0; l < 4; ++l) for (int k = 0; k < 6; ++k) if (hs[l * 8 + k]) fprintf(stderr, " L%d.%s %.1f", l, nm[k], (double)hs[l * 8 + k] / n);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
   const int lds = off * 8;
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_amg_tail), hipFuncAttributeMaxDynamicSharedMemorySize, lds);   // per device, per size
   hipLaunchKernelGGL(k_amg_tail, dim3(1), dim3(FEA_TAIL_T), lds, c->stream, A);
