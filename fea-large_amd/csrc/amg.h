@@ -66,6 +66,10 @@ struct AmgHierarchy {
   int row0 = 0, row1 = 0;                // rows of level 0 this hierarchy covers (the rank's own)
   double *d_z = nullptr;                 // level-0 iterate of the cycle (zero outside the rank's rows)
   double *result = nullptr;              // where the last cycle left z: d_z, or the context's q when the last sweep is fused
+  // the tail's entry-level matrix re-laid out for its product (k_tail_relayout, amg.hip): groups of 16 rows, per group
+  // `slots` blocks per lane, every (slot, 16-byte piece) 64 lanes wide; tail_goff[g] = first slot of group g
+  float *d_tail_ell = nullptr; int *d_tail_goff = nullptr; int tail_groups = 0, tail_slots = 0;
+  bool tail_ell = true;                  // (FEAHIP_AMG_TAIL_ELL=0: the product gathers 36-byte blocks from L2)
   double *d_tail_blob = nullptr;         // the tail levels' read-only arrays in the tail kernel's LDS layout, repacked at every numeric setup
   bool tail_blob = true;                 // (FEAHIP_AMG_TAIL_BLOB=0: every launch gathers them array by array)
   bool fused_post = false;               // post-smoothing product and update in one launch (FEAHIP_AMG_FUSED_POST=1; measured 1.6-2.5 % slower per CG iteration than the two launches)

@@ -336,6 +336,8 @@ struct TailArgs {
   int nl, sweeps;
   unsigned long long *stamps;            // diagnostic build only: [level][8] accumulated s_memtime ticks per phase kind, [32] launches
   const double *blob;                    // the levels' read-only arrays and small matrices in their LDS layout (k_tail_pack), or null
+  const float *ell; const int *goff;     // entry level's matrix by (group of 16 rows, slot, piece, lane) and the groups' first slots, or null
+  int ngroups, o_goff;                   // o_goff: LDS doubles offset of the ngroups + 1 ints
   int blob_lo, blob_n;                   // LDS doubles [blob_lo, blob_lo + blob_n): one contiguous copy per launch
   int lds_doubles;                       // all of it
 };
@@ -476,6 +478,65 @@ __device__ __forceinline__ void t_prolong(const TailLevel &L, const TailLevel &C
     x[k] += over * u0; x[k + 1] += over * u1; x[k + 2] += over * u2;
   }
 }
+// ---- the entry level's product out of a lane-major copy of its matrix ----------------------------------------------
+// Lane (row, sub) of t_spmv multiplies blocks kb + sub, kb + sub + 4, ... of its row.  From the CSR array that is a
+// 36-byte gather per block: ~1 200 load instructions of one CU's texture unit per product, 6.2 us, 19 of a launch's 33.
+// k_tail_relayout writes the same blocks in the order the lanes read them: groups of 16 rows (one wave), per group as
+// many slots as its longest row needs, a slot = three 16-byte pieces (values 0-3, 4-7, value 8 + column) of 64 lanes
+// each; absent blocks are zeros on column 0.  Same blocks, same order of summation, 1 KB per load instruction.
+__global__ void k_tail_relayout(int N, int ngroups, const int *goff, const int *rowptr, const int *colidx, const float *K32, float *ell)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nslots = goff[ngroups];
+  if (t >= nslots * 64) return;
+  const int s = t >> 6, lane = t & 63;
+  int g = 0;
+  while (g + 1 < ngroups && goff[g + 1] <= s) ++g;
+  const int u = s - goff[g], row = 16 * g + (lane >> 2), sub = lane & 3;
+  float v[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (row < N) {
+    const int k = rowptr[row] + sub + 4 * u;
+    if (k < rowptr[row + 1]) {
+      for (int q = 0; q < 9; ++q) v[q] = K32[(size_t)k * 9 + q];
+      v[9] = __int_as_float(colidx[k]);
+    }
+  }
+  float4 *o = reinterpret_cast<float4 *>(ell);
+  for (int j = 0; j < 3; ++j) o[((size_t)s * 3 + j) * 64 + lane] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+}
+__device__ __forceinline__ void t_spmv_ell(const TailArgs &A, const TailLevel &L, double *smem)
+{
+  const int t = threadIdx.x, lane = t & 63, sub = lane & 3;
+  const double *x = T_X(L); double *y = T_Y(L);
+  const int *goff = reinterpret_cast<const int *>(smem + A.o_goff);
+  const float4 *ell = reinterpret_cast<const float4 *>(A.ell);
+  for (int g = t >> 6; g < A.ngroups; g += FEA_TAIL_T / 64) {
+    const int row = 16 * g + (lane >> 2);
+    const int s0 = goff[g], ns = goff[g + 1] - s0;
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int u0 = 0; u0 < ns; u0 += 4) {                 // four slots (twelve loads) in flight
+      float4 p[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int su = s0 + (u0 + u < ns ? u0 + u : u0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) p[u][j] = ell[((size_t)su * 3 + j) * 64 + lane];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u0 + u < ns) {                               // (uniform)
+          const int col = __float_as_int(p[u][2].y);
+          const double x0 = x[col * 3], x1 = x[col * 3 + 1], x2 = x[col * 3 + 2];
+          a0 += (double)p[u][0].x * x0 + (double)p[u][0].y * x1 + (double)p[u][0].z * x2;
+          a1 += (double)p[u][0].w * x0 + (double)p[u][1].x * x1 + (double)p[u][1].y * x2;
+          a2 += (double)p[u][1].z * x0 + (double)p[u][1].w * x1 + (double)p[u][2].x * x2;
+        }
+      }
+    }
+    a0 = dpp_quad_sum(a0); a1 = dpp_quad_sum(a1); a2 = dpp_quad_sum(a2);
+    if (row < L.N && sub < 3) y[row * 3 + sub] = sub == 0 ? a0 : (sub == 1 ? a1 : a2);
+  }
+}
 template <int D>
 __device__ void t_cycle(const TailArgs &A, int l, double *smem)
 {
@@ -501,13 +562,16 @@ __device__ void t_cycle(const TailArgs &A, int l, double *smem)
     for (int s = 0; s < A.sweeps; ++s) { t_spmv(L, smem); __syncthreads(); TS(l, 2); t_smooth_next(L, smem); __syncthreads(); TS(l, 1); }
     return;
   }
+  const bool ell = l == 0 && A.ell != nullptr;          // (uniform)
   for (int g = 0; g < A.gamma[l]; ++g) {
-    t_spmv(L, smem); __syncthreads(); TS(l, 2);
+    if (ell) t_spmv_ell(A, L, smem); else t_spmv(L, smem);
+    __syncthreads(); TS(l, 2);
     t_restrict(L, A.lv[l + 1], smem); __syncthreads(); TS(l, 3);
     if (D > 0) t_cycle<(D > 0 ? D - 1 : 0)>(A, l + 1, smem);
     t_prolong(L, A.lv[l + 1], A.over[l], smem); __syncthreads(); TS(l, 4);
   }
-  t_spmv(L, smem); __syncthreads(); TS(l, 2);
+  if (ell) t_spmv_ell(A, L, smem); else t_spmv(L, smem);
+  __syncthreads(); TS(l, 2);
   t_smooth_next(L, smem); __syncthreads(); TS(l, 1);
 }
 // the levels' read-only arrays and the small matrices, laid out as the kernel's LDS holds them, written to `base`
@@ -526,6 +590,10 @@ __device__ __forceinline__ void t_stage(const TailArgs &A, double *base)
       for (int i = threadIdx.x; i < L.N; i += FEA_TAIL_T) { agg[i] = L.agg[i]; type[i] = (int)L.type[i]; anodes[i] = L.anodes[i]; }
       for (int i = threadIdx.x; i <= L.nagg; i += FEA_TAIL_T) aptr[i] = L.aptr[i];
     }
+  }
+  if (A.goff) {
+    int *sg = reinterpret_cast<int *>(base + A.o_goff);
+    for (int i = threadIdx.x; i <= A.ngroups; i += FEA_TAIL_T) sg[i] = A.goff[i];
   }
   for (int l = 0; l < A.nl; ++l) {                      // small matrices too
     const TailLevel &L = A.lv[l];
@@ -618,6 +686,7 @@ int amg_create(feahip_ctx *c)
   { const char *e = getenv("FEAHIP_AMG_GAMMA_FROM"); if (e) h->gamma_from = atoi(e); }
   { const char *e = getenv("FEAHIP_AMG_GAMMA_UNTIL"); if (e) h->gamma_until = atoi(e); }
   { const char *e = getenv("FEAHIP_AMG_TAIL_BLOB"); h->tail_blob = !(e && atoi(e) == 0); }
+  { const char *e = getenv("FEAHIP_AMG_TAIL_ELL"); h->tail_ell = !(e && atoi(e) == 0); }
   { const char *e = getenv("FEAHIP_AMG_FUSED_POST"); h->fused_post = e && atoi(e) != 0; }
   { const char *e = getenv("FEAHIP_AMG_SWEEPS"); if (e) h->coarse_sweeps = atoi(e); }
   // the levels the one-workgroup kernel takes: from the first level below the finest of at most FEA_TAIL_ROWS rows
@@ -679,6 +748,23 @@ int amg_create(feahip_ctx *c)
   }
   if ((rc = zeros(c, &h->d_z, (size_t)c->ndof, h->bytes))) return rc;
   if ((rc = zeros(c, &h->d_pw, (size_t)c->ndof, h->bytes))) return rc;
+  if (h->tail_from >= 0 && h->tail_ell && h->coarse_f32) {
+    const HostAmgLevel &S = hl[(size_t)h->tail_from];
+    const int G = (S.N + 15) / 16;
+    std::vector<int> goff((size_t)G + 1, 0);
+    int worst = 0;
+    for (int g = 0; g < G; ++g) {
+      int ns = 0;
+      for (int r = 16 * g; r < std::min(S.N, 16 * g + 16); ++r) ns = std::max(ns, (S.rowptr[(size_t)r + 1] - S.rowptr[(size_t)r] + 3) / 4);
+      goff[(size_t)g + 1] = goff[(size_t)g] + ns; worst = std::max(worst, ns);
+    }
+    if (worst <= 32) {                                  // (rows of more than 128 blocks have a chunk of their own elsewhere; here they keep the CSR product)
+      h->tail_groups = G; h->tail_slots = goff[(size_t)G];
+      if ((rc = up(c, &h->d_tail_goff, goff, h->bytes))) return rc;
+      FEA_HIP_CHECK(c, hipMalloc((void **)&h->d_tail_ell, sizeof(float) * 12 * 64 * (size_t)std::max(h->tail_slots, 1)));
+      h->bytes += (long long)(sizeof(float) * 12 * 64 * (size_t)h->tail_slots);
+    }
+  }
   if (h->tail_from >= 0 && h->tail_blob) {
     const TailArgs A = tail_args(c);
     if ((rc = zeros(c, &h->d_tail_blob, (size_t)A.blob_n, h->bytes))) return rc;
@@ -699,6 +785,8 @@ void amg_destroy(feahip_ctx *c)
   if (h->d_z) (void)hipFree(h->d_z);
   if (h->d_pw) (void)hipFree(h->d_pw);
   if (h->d_tail_blob) (void)hipFree(h->d_tail_blob);
+  if (h->d_tail_ell) (void)hipFree(h->d_tail_ell);
+  if (h->d_tail_goff) (void)hipFree(h->d_tail_goff);
   delete h;
   c->amg = nullptr;
 }
@@ -770,6 +858,10 @@ static int amg_numeric(feahip_ctx *c)
     }
     L.omega = 4.0 / (3.0 * 1.1 * lam);        // 10 % margin: the power iteration approaches lambda_max from below
   }
+  if (h->d_tail_ell) {                                   // the tail's entry-level matrix for this K, lane-major
+    const AmgLevel &L = h->lv[(size_t)h->tail_from];
+    if (L.K32) hipLaunchKernelGGL(k_tail_relayout, G256(h->tail_slots * 64), L.N, h->tail_groups, h->d_tail_goff, L.rowptr, L.colidx, L.K32, h->d_tail_ell);
+  }
   if (h->d_tail_blob) {                                  // the tail's read-only arrays for this K, in its LDS layout
     const TailArgs A = tail_args(c);
     hipLaunchKernelGGL(k_tail_pack, dim3(1), dim3(FEA_TAIL_T), 0, c->stream, A, h->d_tail_blob);
@@ -811,6 +903,7 @@ static TailArgs tail_args(feahip_ctx *c)
   off += off & 1;
   A.blob_lo = off;
   for (int k = 0; k < nl; ++k) { const AmgLevel &L = h->lv[h->tail_from + k]; A.lv[k].o_aux = off; off += T_AUX_DOUBLES(L.N, L.Nc / 2); }
+  A.o_goff = off; off += (h->tail_groups + 2) / 2 + 1;
   for (int k = nl - 1; k >= 0; --k) {                   // small matrices too, the most visited first, while they fit
     const AmgLevel &L = h->lv[h->tail_from + k];
     const int need = (L.nnzb * 10 + 1) / 2 + 1;
@@ -818,6 +911,10 @@ static TailArgs tail_args(feahip_ctx *c)
   }
   off += off & 1;
   A.blob_n = off - A.blob_lo;
+  // the entry level's product reads the lane-major copy unless that level's matrix sits in LDS anyway
+  const bool ell = h->d_tail_ell && A.lv[0].o_K < 0;
+  A.ell = ell ? h->d_tail_ell : (const float *)nullptr; A.goff = ell ? h->d_tail_goff : (const int *)nullptr;
+  A.ngroups = ell ? h->tail_groups : 0;
   A.lds_doubles = off;
   A.nl = nl; A.sweeps = h->coarse_sweeps;
   A.blob = h->d_tail_blob;
