@@ -188,12 +188,6 @@ struct bf16_t { unsigned short v[4]; };
 #define FEA_SPMV_STAGED 1      // bit 0: double matrices, 1: float, 2: bfloat16 (measured: only the 72-byte blocks gain)
 #endif
 typedef double spmv_v2d __attribute__((ext_vector_type(2)));
-#ifndef FEA_VEC_BY_DOF
-#define FEA_VEC_BY_DOF 1
-#endif
-#ifndef SPMV_HOIST
-#define SPMV_HOIST 1
-#endif
 template <class TK>
 __device__ __forceinline__ void load_block9(const TK *K, size_t kk, double (&v)[9])
 {
@@ -290,7 +284,7 @@ __device__ __forceinline__ void spmv_body(int chunk0, int nchunks, const int *ch
     // lane t < 3 rows sums component t % 3 of row r0 + t / 3 (a chunk has at most FEA_CHUNK_ROWS = 16 rows: one pass);
     // its block range is loaded here, with everything else, not after the products
     int kb = 0, ke = 0;
-    if (SPMV_HOIST && lane < (r1 - r0) * 3) { kb = rowptr[r0 + lane / 3] - b0; ke = rowptr[r0 + lane / 3 + 1] - b0; }
+    if (lane < (r1 - r0) * 3) { kb = rowptr[r0 + lane / 3] - b0; ke = rowptr[r0 + lane / 3 + 1] - b0; }
     double jm[3] = {0, 0, 0}, jr = 0, jx = 0;              // JAC: the lane's row of D^-1, r and x, likewise
     if constexpr (JAC) {
       if (lane < (r1 - r0) * 3) {
@@ -367,10 +361,9 @@ __device__ __forceinline__ void spmv_body(int chunk0, int nchunks, const int *ch
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     if constexpr (JAC) {
       const int t = lane, nt = (r1 - r0) * 3;            // <= 48: one pass
-      const int row = r0 + t / 3, i = t % 3;
+      const int i = t % 3;
       double res = 0.0;
       if (t < nt) {
-        if (!SPMV_HOIST) { kb = rowptr[row] - b0; ke = rowptr[row + 1] - b0; }
         double acc = 0;
         for (int k = kb; k < ke; ++k) acc += tP[k * 3 + i];
         res = jr - acc;
@@ -385,7 +378,6 @@ __device__ __forceinline__ void spmv_body(int chunk0, int nchunks, const int *ch
     const int t = lane;
     if (t < (r1 - r0) * 3) {
       const int i = t % 3;
-      if (!SPMV_HOIST) { kb = rowptr[r0 + t / 3] - b0; ke = rowptr[r0 + t / 3 + 1] - b0; }
       double acc = 0;
       for (int k = kb; k < ke; ++k) acc += tP[k * 3 + i];
       y[(size_t)r0 * 3 + t] = acc;
@@ -592,7 +584,6 @@ void k_cg_update(int a0, int a1, int it, int n_pq, const double *p, const double
   const double rz = scal[it & 1];
   const double alpha = rz / pq;
   double srz = 0, srr = 0;
-#if FEA_VEC_BY_DOF
   // lane <-> scalar dof, 21 nodes per wave and step: every vector is read as one contiguous run per instruction, and
   // so is D^-1 (row i of node a's block is the three doubles at 3 (3a + i)); the three residual components of a node
   // meet by shuffles.  (A lane per node read its nine inverse values with a 72-byte stride between lanes.)
@@ -613,23 +604,6 @@ void k_cg_update(int a0, int a1, int it, int n_pq, const double *p, const double
     }
     if (on) { srz += rv * z; srr += rv * rv; if (zq) zq[k] = z; }
   }
-#else
-  for (int a = a0 + blockIdx.x * 256 + threadIdx.x; a < a1; a += gridDim.x * 256) {
-    const double *m = minv + (size_t)a * 9;
-    double rv[3];
-    for (int i = 0; i < 3; ++i) {
-      const size_t k = (size_t)a * 3 + i;
-      x[k] += alpha * p[k];
-      rv[i] = r[k] - alpha * q[k];
-      r[k] = rv[i];
-    }
-    for (int i = 0; i < 3; ++i) {
-      const double z = minv ? m[3 * i] * rv[0] + m[3 * i + 1] * rv[1] + m[3 * i + 2] * rv[2] : rv[i];
-      srz += rv[i] * z; srr += rv[i] * rv[i];
-      if (zq) zq[(size_t)a * 3 + i] = z;
-    }
-  }
-#endif
   srz = block_sum(srz, scratch); srr = block_sum(srr, scratch);
   if (threadIdx.x == 0) { part[RB + blockIdx.x] = srz; part[2 * RB + blockIdx.x] = srr; }
 }
@@ -649,7 +623,7 @@ void k_cg_direction(int a0, int a1, int it, int nparts, const double *r, const d
   const bool broke = !(rz_new == rz_new) || !(rr == rr) || rz_old == 0.0;
   if (!stop && !broke) {
     const double beta = rz_new / rz_old;
-    if (FEA_VEC_BY_DOF && !minv) {                      // z is given: one contiguous run per instruction
+    if (!minv) {                                        // z is given: one contiguous run per instruction
       for (size_t k = (size_t)a0 * 3 + blockIdx.x * 256 + threadIdx.x; k < (size_t)a1 * 3; k += (size_t)gridDim.x * 256)
         p[k] = r[k] + beta * p[k];
     } else
@@ -702,7 +676,6 @@ void k_cgcg_update(int a0, int a1, int it, const double *z, const double *w, con
     broke = !(alpha == alpha) || !(beta == beta) || alpha == 0.0;
   }
   double sg = 0, srr = 0;
-#if FEA_VEC_BY_DOF
   if (!stop && !broke) {                                // lane <-> scalar dof, 21 nodes per wave and step (k_cg_update)
     const int lane = threadIdx.x & 63, i = lane % 3;
     const bool lane_on = lane < 63;
@@ -727,30 +700,6 @@ void k_cgcg_update(int a0, int a1, int it, const double *z, const double *w, con
       }
     }
   }
-#else
-  if (!stop && !broke) {
-    for (int a = a0 + blockIdx.x * 256 + threadIdx.x; a < a1; a += gridDim.x * 256) {
-      const double *m = minv + (size_t)a * 9;
-      double rv[3];
-      for (int i = 0; i < 3; ++i) {
-        const size_t k = (size_t)a * 3 + i;
-        const double pk = z[k] + beta * p[k], sk = w[k] + beta * s[k];
-        p[k] = pk; s[k] = sk;
-        x[k] += alpha * pk;
-        rv[i] = r[k] - alpha * sk;
-        r[k] = rv[i];
-      }
-      for (int i = 0; i < 3; ++i) {
-        srr += rv[i] * rv[i];
-        if (minv) {                                   // block-Jacobi: z = M r here; multigrid: the cycle follows
-          const double zz = m[3 * i] * rv[0] + m[3 * i + 1] * rv[1] + m[3 * i + 2] * rv[2];
-          znew[(size_t)a * 3 + i] = zz;
-          sg += rv[i] * zz;
-        }
-      }
-    }
-  }
-#endif
   sg = block_sum(sg, scratch); srr = block_sum(srr, scratch);
   if (threadIdx.x == 0) { part[RB + blockIdx.x] = sg; part[2 * RB + blockIdx.x] = srr; }
   // the scalars of this iteration go to the other ping-pong slots; the flag is read at kernel entry only
