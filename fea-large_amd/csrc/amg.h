@@ -70,6 +70,8 @@ struct AmgHierarchy {
   // `slots` blocks per lane, every (slot, 16-byte piece) 64 lanes wide; tail_goff[g] = first slot of group g
   float *d_tail_ell = nullptr; int *d_tail_goff = nullptr; int tail_groups = 0, tail_slots = 0;
   bool tail_ell = true;                  // (FEAHIP_AMG_TAIL_ELL=0: the product gathers 36-byte blocks from L2)
+  double *d_tail_cop = nullptr; int tail_cop_n = 0;   // the coarsest level's smoothing procedure as one dense operator (k_tail_coarse_op), n x n, transposed
+  bool tail_cop = true;                  // (FEAHIP_AMG_TAIL_COP=0: the sweeps one after the other)
   double *d_tail_blob = nullptr;         // the tail levels' read-only arrays in the tail kernel's LDS layout, repacked at every numeric setup
   bool tail_blob = true;                 // (FEAHIP_AMG_TAIL_BLOB=0: every launch gathers them array by array)
   bool fused_post = false;               // post-smoothing product and update in one launch (FEAHIP_AMG_FUSED_POST=1; measured 1.6-2.5 % slower per CG iteration than the two launches)

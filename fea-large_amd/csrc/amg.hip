@@ -338,6 +338,7 @@ struct TailArgs {
   const double *blob;                    // the levels' read-only arrays and small matrices in their LDS layout (k_tail_pack), or null
   const float *ell; const int *goff;     // entry level's matrix by (group of 16 rows, slot, piece, lane) and the groups' first slots, or null
   int ngroups, o_goff;                   // o_goff: LDS doubles offset of the ngroups + 1 ints
+  const double *cop; int cop_n, o_cop;   // the coarsest level's procedure as a dense n x n operator (transposed), its LDS offset; or null / -1
   int blob_lo, blob_n;                   // LDS doubles [blob_lo, blob_lo + blob_n): one contiguous copy per launch
   int lds_doubles;                       // all of it
 };
@@ -545,7 +546,16 @@ __device__ void t_cycle(const TailArgs &A, int l, double *smem)
     // a coarsest level of at most 16 block rows (10 on the 10M-tet block, visited 16 times per cycle) is the work of
     // one wave: its 1 + 2 * sweeps steps follow each other in program order (a wave's LDS operations complete in
     // order), the other fifteen waves wait at ONE barrier instead of taking part in five
-    if (threadIdx.x < 64) {
+    if (A.cop && threadIdx.x < 64) {
+      // ... and the whole procedure is ONE linear map of 3N <= 48 numbers (k_tail_coarse_op): a dense product out of LDS
+      const int n = A.cop_n, i = threadIdx.x;
+      const double *B = smem + A.o_cop, *r = T_R(L);
+      if (i < n) {
+        double a = 0;
+        for (int j = 0; j < n; ++j) a += B[j * n + i] * r[j];
+        T_X(L)[i] = a;
+      }
+    } else if (threadIdx.x < 64) {
       t_smooth_first(L, smem);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       for (int s = 0; s < A.sweeps; ++s) {
@@ -591,6 +601,10 @@ __device__ __forceinline__ void t_stage(const TailArgs &A, double *base)
       for (int i = threadIdx.x; i <= L.nagg; i += FEA_TAIL_T) aptr[i] = L.aptr[i];
     }
   }
+  if (A.cop) {
+    double *sc = base + A.o_cop;
+    for (int i = threadIdx.x; i < A.cop_n * A.cop_n; i += FEA_TAIL_T) sc[i] = A.cop[i];
+  }
   if (A.goff) {
     int *sg = reinterpret_cast<int *>(base + A.o_goff);
     for (int i = threadIdx.x; i <= A.ngroups; i += FEA_TAIL_T) sg[i] = A.goff[i];
@@ -603,6 +617,47 @@ __device__ __forceinline__ void t_stage(const TailArgs &A, double *base)
     for (int i = threadIdx.x; i < L.nnzb * 9; i += FEA_TAIL_T) sK[i] = L.K32[i];
     for (int i = threadIdx.x; i < L.nnzb; i += FEA_TAIL_T) sCol[i] = L.colidx[i];
   }
+}
+// The coarsest level's procedure -- x = omega D^-1 r, then `sweeps` times x += omega D^-1 (r - K x) -- is a fixed linear
+// map x = B r of 3N <= 48 numbers: B_0 = omega D^-1, B_{s+1} = B_s + omega D^-1 (I - K B_s).  Formed densely once per
+// numeric setup (one workgroup, LDS), stored transposed; a visit of that level is then one dense product instead of
+// 1 + 2 sweeps steps that each wait for the one before (2.8 us per visit, sixteen visits per cycle).
+#define T_COP_MAX 48
+__global__ __launch_bounds__(256)
+void k_tail_coarse_op(TailLevel L, int sweeps, double *cop)
+{
+  __shared__ double sA[T_COP_MAX * T_COP_MAX], sB[T_COP_MAX * T_COP_MAX], sT[T_COP_MAX * T_COP_MAX];
+  const int n = 3 * L.N, t = threadIdx.x;
+  for (int i = t; i < n * n; i += 256) { sA[i] = 0.0; sB[i] = 0.0; }
+  __syncthreads();
+  for (int k = t; k < L.nnzb; k += 256) {                // dense K (a thread per block; blocks of a row are distinct columns)
+    int row = 0;
+    while (L.rowptr[row + 1] <= k) ++row;
+    const int col = L.colidx[k];
+    for (int q = 0; q < 9; ++q)
+      sA[(3 * row + q / 3) * n + 3 * col + q % 3] = L.K32 ? (double)L.K32[(size_t)k * 9 + q] : L.K[(size_t)k * 9 + q];
+  }
+  for (int i = t; i < L.N * 9; i += 256) {               // B_0 = omega D^-1 (block diagonal)
+    const int a = i / 9, q = i % 9;
+    sB[(3 * a + q / 3) * n + 3 * a + q % 3] = L.omega * L.minv[i];
+  }
+  __syncthreads();
+  for (int s = 0; s < sweeps; ++s) {
+    for (int e = t; e < n * n; e += 256) {               // T = I - K B
+      const int i = e / n, j = e % n;
+      double a = i == j ? 1.0 : 0.0;
+      for (int m = 0; m < n; ++m) a -= sA[i * n + m] * sB[m * n + j];
+      sT[e] = a;
+    }
+    __syncthreads();
+    for (int e = t; e < n * n; e += 256) {               // B += omega D^-1 T (the 3x3 block row of node i / 3)
+      const int i = e / n, j = e % n, a = i / 3;
+      const double *m = L.minv + (size_t)a * 9 + 3 * (i % 3);
+      sB[e] += L.omega * (m[0] * sT[(3 * a) * n + j] + m[1] * sT[(3 * a + 1) * n + j] + m[2] * sT[(3 * a + 2) * n + j]);
+    }
+    __syncthreads();
+  }
+  for (int e = t; e < n * n; e += 256) cop[(e % n) * n + e / n] = sB[e];    // transposed: lane i of the product reads consecutive words
 }
 __global__ __launch_bounds__(FEA_TAIL_T)
 void k_tail_pack(TailArgs A, double *blob)
@@ -687,6 +742,7 @@ int amg_create(feahip_ctx *c)
   { const char *e = getenv("FEAHIP_AMG_GAMMA_UNTIL"); if (e) h->gamma_until = atoi(e); }
   { const char *e = getenv("FEAHIP_AMG_TAIL_BLOB"); h->tail_blob = !(e && atoi(e) == 0); }
   { const char *e = getenv("FEAHIP_AMG_TAIL_ELL"); h->tail_ell = !(e && atoi(e) == 0); }
+  { const char *e = getenv("FEAHIP_AMG_TAIL_COP"); h->tail_cop = !(e && atoi(e) == 0); }
   { const char *e = getenv("FEAHIP_AMG_FUSED_POST"); h->fused_post = e && atoi(e) != 0; }
   { const char *e = getenv("FEAHIP_AMG_SWEEPS"); if (e) h->coarse_sweeps = atoi(e); }
   // the levels the one-workgroup kernel takes: from the first level below the finest of at most FEA_TAIL_ROWS rows
@@ -765,6 +821,10 @@ int amg_create(feahip_ctx *c)
       h->bytes += (long long)(sizeof(float) * 12 * 64 * (size_t)h->tail_slots);
     }
   }
+  if (h->tail_from >= 0 && h->tail_cop && hl.back().N <= 16 && hl.back().Sc == 0 && (int)hl.size() - 1 > h->tail_from) {
+    h->tail_cop_n = 3 * hl.back().N;
+    if ((rc = zeros(c, &h->d_tail_cop, (size_t)h->tail_cop_n * h->tail_cop_n, h->bytes))) return rc;
+  }
   if (h->tail_from >= 0 && h->tail_blob) {
     const TailArgs A = tail_args(c);
     if ((rc = zeros(c, &h->d_tail_blob, (size_t)A.blob_n, h->bytes))) return rc;
@@ -786,6 +846,7 @@ void amg_destroy(feahip_ctx *c)
   if (h->d_pw) (void)hipFree(h->d_pw);
   if (h->d_tail_blob) (void)hipFree(h->d_tail_blob);
   if (h->d_tail_ell) (void)hipFree(h->d_tail_ell);
+  if (h->d_tail_cop) (void)hipFree(h->d_tail_cop);
   if (h->d_tail_goff) (void)hipFree(h->d_tail_goff);
   delete h;
   c->amg = nullptr;
@@ -862,6 +923,10 @@ static int amg_numeric(feahip_ctx *c)
     const AmgLevel &L = h->lv[(size_t)h->tail_from];
     if (L.K32) hipLaunchKernelGGL(k_tail_relayout, G256(h->tail_slots * 64), L.N, h->tail_groups, h->d_tail_goff, L.rowptr, L.colidx, L.K32, h->d_tail_ell);
   }
+  if (h->d_tail_cop) {                                   // the coarsest level's procedure as one operator, for this K
+    const TailArgs A = tail_args(c);
+    hipLaunchKernelGGL(k_tail_coarse_op, dim3(1), dim3(256), 0, c->stream, A.lv[A.nl - 1], h->coarse_sweeps, h->d_tail_cop);
+  }
   if (h->d_tail_blob) {                                  // the tail's read-only arrays for this K, in its LDS layout
     const TailArgs A = tail_args(c);
     hipLaunchKernelGGL(k_tail_pack, dim3(1), dim3(FEA_TAIL_T), 0, c->stream, A, h->d_tail_blob);
@@ -904,6 +969,9 @@ static TailArgs tail_args(feahip_ctx *c)
   A.blob_lo = off;
   for (int k = 0; k < nl; ++k) { const AmgLevel &L = h->lv[h->tail_from + k]; A.lv[k].o_aux = off; off += T_AUX_DOUBLES(L.N, L.Nc / 2); }
   A.o_goff = off; off += (h->tail_groups + 2) / 2 + 1;
+  A.cop = h->d_tail_cop; A.cop_n = h->tail_cop_n; A.o_cop = -1;
+  if (A.cop && (off + A.cop_n * A.cop_n) * 8 <= 156 * 1024) { A.o_cop = off; off += A.cop_n * A.cop_n; }
+  else A.cop = nullptr;
   for (int k = nl - 1; k >= 0; --k) {                   // small matrices too, the most visited first, while they fit
     const AmgLevel &L = h->lv[h->tail_from + k];
     const int need = (L.nnzb * 10 + 1) / 2 + 1;

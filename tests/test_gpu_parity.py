@@ -252,11 +252,11 @@ def test_multigrid_variants_are_the_same_preconditioner(monkeypatch):
     its = {}
     for name, env in (("default", {}), ("no_tail", {"FEAHIP_AMG_TAIL": "0"}), ("fused_post", {"FEAHIP_AMG_FUSED_POST": "1"}),
                       ("v_below_1", {"FEAHIP_AMG_GAMMA_UNTIL": "1"}),
-                      ("tail_csr", {"FEAHIP_AMG_TAIL_ELL": "0", "FEAHIP_AMG_TAIL_BLOB": "0"}),
+                      ("tail_csr", {"FEAHIP_AMG_TAIL_ELL": "0", "FEAHIP_AMG_TAIL_BLOB": "0", "FEAHIP_AMG_TAIL_COP": "0"}),
                       ("f32", {"FEAHIP_AMG_FINE_BITS": "32"}),
                       ("f64", {"FEAHIP_AMG_FINE_BITS": "64"}), ("shallow", {"FEAHIP_AMG_COARSEST": "1500", "FEAHIP_AMG_SWEEPS": "12"})):
         for k in ("FEAHIP_AMG_TAIL", "FEAHIP_AMG_FINE_BITS", "FEAHIP_AMG_COARSEST", "FEAHIP_AMG_SWEEPS", "FEAHIP_AMG_FUSED_POST",
-                  "FEAHIP_AMG_GAMMA_UNTIL", "FEAHIP_AMG_TAIL_ELL", "FEAHIP_AMG_TAIL_BLOB"):
+                  "FEAHIP_AMG_GAMMA_UNTIL", "FEAHIP_AMG_TAIL_ELL", "FEAHIP_AMG_TAIL_BLOB", "FEAHIP_AMG_TAIL_COP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -268,7 +268,9 @@ def test_multigrid_variants_are_the_same_preconditioner(monkeypatch):
         assert res < 1e-14, name
         assert rel(t.solution(), o.solution()) < U_TOL, name
         t.close()
-    assert its["default"] == its["no_tail"] == its["tail_csr"], its   # (the lane-major copy of the tail's matrix: same sums, same order)
+    # the one-launch tail against the same steps kernel by kernel: the same operator (its coarsest level as one dense
+    # product: a different association), iteration counts within one
+    assert abs(its["default"] - its["no_tail"]) <= 1 and its["no_tail"] == its["tail_csr"], its
     assert abs(its["fused_post"] - its["default"]) <= 1, its          # same sums, the update in the same launch
     assert abs(its["f32"] - its["default"]) <= 6 and abs(its["f64"] - its["default"]) <= 6, its
 
