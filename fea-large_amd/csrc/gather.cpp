@@ -665,6 +665,41 @@ extern "C" int feahip_host_assembly_digest(int n_nodes, int n_elems, int npe, co
   return FEAHIP_OK;
 }
 
+// Host-only (no device): what the gather maps (4-node, or 10-node / 8-node) look like for a mesh in the numbering it is given --
+// stats[0..5] = chunks, element evaluations, distinct elements, rows, chunks repeating their predecessor's words, map
+// bytes; rows_hist[FEA_G_MAX_ROWS + 1] (may be null) = chunks by row count.  What the numbering of an unstructured mesh
+// is judged by before a device sees it (tools/gather_stats.py).
+extern "C" int feahip_host_gather_stats(int n_nodes, int n_elems, int npe, const int *elements, long long *stats, int *rows_hist)
+{
+  if (!elements || !stats || n_nodes <= 0 || n_elems <= 0 || (npe != 4 && npe != 10 && npe != 8)) return FEAHIP_EINVAL;
+  HostPattern hp;
+  std::string err;
+  int rc = build_host_pattern(n_nodes, n_elems, npe, elements, hp, err);
+  if (rc) return rc;
+  const std::vector<int> *first_row;
+  HostGather hg;
+  HostGather10 hq;
+  if (npe == 4) {
+    build_host_gather(n_nodes, n_elems, elements, hp, 0, n_nodes, hg);
+    if (!hg.ok) return FEAHIP_EINVAL;
+    stats[0] = hg.nchunks; stats[1] = hg.total_evals; stats[2] = hg.distinct_elems;
+    stats[4] = hg.same_as_previous; stats[5] = (long long)hg.blob.size();
+    first_row = &hg.first_row;
+  } else {
+    build_host_gather10(n_nodes, n_elems, npe, elements, hp, 0, n_nodes, hq);
+    if (!hq.ok) return FEAHIP_EINVAL;
+    stats[0] = hq.nchunks; stats[1] = hq.total_evals; stats[2] = hq.distinct_elems;
+    stats[4] = 0; stats[5] = (long long)hq.blob.size();
+    first_row = &hq.first_row;
+  }
+  stats[3] = n_nodes;
+  if (rows_hist) {
+    for (int l = 0; l <= FEA_G_MAX_ROWS; ++l) rows_hist[l] = 0;
+    for (size_t p = 0; p + 1 < first_row->size(); ++p) ++rows_hist[std::min((*first_row)[p + 1] - (*first_row)[p], FEA_G_MAX_ROWS)];
+  }
+  return FEAHIP_OK;
+}
+
 #ifdef FEAHIP_DEBUG
 // diagnostic build only, host only: one chunk's map record and the layout, for the LDS bank model (dbg/lds_model.py)
 extern "C" int feahip_debug_gather_record_host(int n_nodes, int n_elems, const int *elements, int chunk, int *layout_ints,

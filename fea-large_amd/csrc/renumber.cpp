@@ -13,12 +13,15 @@
 // non-zero coordinate differences between the nodes of an element: exact on a lattice; cell counts checked and the
 // cells rescaled when the mesh is not one); cells in lexicographic order with the longest axis of the box slowest
 // (a contiguous id range stays a slab across the long axis: what the row shard cuts); nodes inside a cell in the same
-// order of their sub-positions, ties by original id.  On a structured block this reproduces a brick numbering
-// exactly; on an unstructured mesh it is a bucket sort into compact boxes of ~bx*by*bz nodes.  Deterministic in
-// (coordinates, connectivity).
+// order of their sub-positions, ties by original id.  On a structured block (exact, or with noise: origin and spacing
+// are fitted to the nodes) this reproduces a brick numbering exactly.  A mesh whose nodes sit on no lattice on any axis
+// (a TetGen deck) is numbered by recursive coordinate bisection into leaves of the chunk length instead (rcb_order
+// below; FEAHIP_NUMBERING_RCB=0 keeps the cells, which are a bucket sort into boxes of ~bx*by*bz nodes there).
+// Deterministic in (coordinates, connectivity).
 #include "feahip_internal.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <thread>
 
@@ -29,6 +32,123 @@ double median_inplace(std::vector<double> &v)
   const size_t m = v.size() / 2;
   std::nth_element(v.begin(), v.begin() + m, v.end());
   return v[m];
+}
+
+// Unstructured meshes: recursive coordinate bisection into leaves of exactly `leaf` nodes.  The bucket sort below gives a
+// lattice its bricks; on a TetGen mesh its cells hold anything between a few and a hundred nodes, a run of 64
+// consecutive ids straddles two or three of them, and the chunks the gather maps cut out of it (gather.cpp, pass A)
+// end at ~50 rows with 1.90 evaluations per element.  Here every range of nodes is split across the longest side of
+// ITS bounding box at a multiple of the leaf size, so every leaf but the last of a range is full and as close to a cube
+// as the nodes allow; the leaves follow one another in the order of the tree (neighbours in space stay neighbours in
+// L2), and the first cuts of a slender body are across its long axis: id ranges are slabs, as the row shard wants.
+// Inside a leaf the bisection goes on by halves down to single nodes (the first 32, 48, 56 ids of a leaf are compact
+// too).  Deterministic and independent of the caller's ids (ties by the other coordinates; only coincident points fall back
+// to the id); the threads work on disjoint ranges.
+struct RcbRange { int lo, hi; };
+int rcb_split(const double *X, int *idx, RcbRange r, int leaf)
+{
+  const int m = r.hi - r.lo;
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int i = r.lo; i < r.hi; ++i)
+    for (int k = 0; k < 3; ++k) { const double x = X[(size_t)idx[i] * 3 + k]; lo[k] = std::min(lo[k], x); hi[k] = std::max(hi[k], x); }
+  int ax = 1;                                                  // ties: y, z, x -- the order of the reference's bar
+  if (hi[2] - lo[2] > (hi[ax] - lo[ax]) * (1.0 + 1e-9)) ax = 2;
+  if (hi[0] - lo[0] > (hi[ax] - lo[ax]) * (1.0 + 1e-9)) ax = 0;
+  const int left = m > leaf ? ((m + leaf - 1) / leaf / 2) * leaf : m / 2;
+  const int ax1 = (ax + 1) % 3, ax2 = (ax + 2) % 3;            // ties (the nodes of a flat face): by the other coordinates, then by id
+  std::nth_element(idx + r.lo, idx + r.lo + left, idx + r.hi, [&](int a, int b) {
+    const double *pa = X + (size_t)a * 3, *pb = X + (size_t)b * 3;
+    if (pa[ax] != pb[ax]) return pa[ax] < pb[ax];
+    if (pa[ax1] != pb[ax1]) return pa[ax1] < pb[ax1];
+    if (pa[ax2] != pb[ax2]) return pa[ax2] < pb[ax2];
+    return a < b;
+  });
+  return left;
+}
+void rcb_order(const double *X, int *idx, int n, int leaf)
+{
+  unsigned hw = std::thread::hardware_concurrency();
+  const int nt = n < (1 << 16) ? 1 : (int)std::min<unsigned>(hw ? hw : 4, 32);
+  std::vector<RcbRange> todo(1, RcbRange{0, n});
+  while (nt > 1 && (int)todo.size() < 8 * nt) {                // the top of the tree, level by level
+    std::vector<RcbRange> next;
+    bool any = false;
+    for (const RcbRange &r : todo) {
+      if (r.hi - r.lo <= 4 * leaf) { next.push_back(r); continue; }
+      const int left = rcb_split(X, idx, r, leaf);
+      next.push_back({r.lo, r.lo + left}); next.push_back({r.lo + left, r.hi});
+      any = true;
+    }
+    todo.swap(next);
+    if (!any) break;
+  }
+  auto finish = [&](RcbRange top) {
+    std::vector<RcbRange> stack(1, top);
+    while (!stack.empty()) {
+      const RcbRange r = stack.back();
+      stack.pop_back();
+      if (r.hi - r.lo <= 1) continue;
+      const int left = rcb_split(X, idx, r, leaf);
+      stack.push_back({r.lo + left, r.hi});
+      stack.push_back({r.lo, r.lo + left});
+    }
+  };
+  if (nt <= 1) { for (const RcbRange &r : todo) finish(r); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&, t] { for (size_t i = (size_t)t; i < todo.size(); i += (size_t)nt) finish(todo[i]); });
+  for (auto &x : th) x.join();
+}
+
+// The leaf size for 4-node tetrahedra.  A chunk is bounded in ELEMENTS as well as rows (the records of the elements around
+// its rows fill the LDS: FEA_G_ELEMS_TARGET), and where a mesh is dense (the inside of the reference's TetGen deck: ~750
+// elements around 64 nodes, ~450 at its faces) a leaf of 64 does not fit: pass A cuts it into 52 + 12 rows, and the 10M
+// mesh ends with 53 rows per chunk.  A leaf a few rows SHORT of the row limit leaves pass A room to move a boundary: a
+// leaf that is too dense hands its last rows to its neighbour.  Measured on that deck (chunks against leaves, pass A's
+// own partition): leaves of 56-59 all end as one chunk, of 60 +0.4 %, 61 +2.5 %, 62 +10 %, 64 +20 % -- 60 is the
+// best there (34 325 chunks of 60 rows and 1.75 evaluations per element on the 10M mesh, where the cells gave 41 393
+// of 50 and 1.90).  The rule that picks it: after one bisection with leaves of 64, a few blocks of 8 192 consecutive
+// ids (compact regions: unions of subtrees) spread over the id range are bisected again with every even candidate size
+// L and the elements around every leaf are counted; the largest L whose share of leaves that do not fit is within what
+// 64 - L rows of room absorb (4 % per row: 62 -> 8 %, 60 -> 16 %; 1 % for 64 itself) wins.  Measured and dropped:
+// leaves bounded by the element incidences of their nodes (a weight limit in the bisection: the incidences predict
+// the distinct elements too loosely); the prefixes of the 64-leaves as a model of shorter leaves (a prefix is half +
+// quarter + ... of a leaf, a slab, not a cube); a greedy walk as a model of pass A (it cuts 60.7 rows whatever the leaf).
+int rcb_pick_leaf(int N, int E, const int *conn, const double *X, const int *order, int leaf0, int elem_cap)
+{
+  const int block = 8192;
+  if (N < 4 * leaf0) return leaf0;
+  std::vector<int> incptr((size_t)N + 1, 0);
+  for (size_t q = 0; q < (size_t)E * 4; ++q) ++incptr[(size_t)conn[q] + 1];
+  for (int a = 0; a < N; ++a) incptr[(size_t)a + 1] += incptr[a];
+  std::vector<int> inc((size_t)E * 4), fill(incptr.begin(), incptr.end() - 1);
+  for (int e = 0; e < E; ++e)
+    for (int k = 0; k < 4; ++k) inc[(size_t)fill[conn[(size_t)e * 4 + k]]++] = e;
+  std::vector<int>().swap(fill);
+  const int nblocks = std::max(1, std::min(8, N / block)), blen = std::min(N, block);
+  std::vector<int> stamp((size_t)E, -1), ids((size_t)blen);
+  int serial = 0;
+  for (int L = leaf0; L >= leaf0 / 2; L -= 2) {
+    long long leaves = 0, misfits = 0;
+    for (int b = 0; b < nblocks; ++b) {
+      const int start = nblocks == 1 ? 0 : (int)((long long)(N - blen) * b / (nblocks - 1));
+      for (int i = 0; i < blen; ++i) ids[i] = order[(size_t)start + i];
+      std::sort(ids.begin(), ids.end());                        // the result must not depend on the order the block came in
+      rcb_order(X, ids.data(), blen, L);
+      for (int l0 = 0; l0 < blen; l0 += L, ++serial, ++leaves) {
+        const int l1 = std::min(blen, l0 + L);
+        int nel = 0;
+        for (int i = l0; i < l1; ++i)
+          for (int q = incptr[ids[i]]; q < incptr[ids[i] + 1]; ++q)
+            if (stamp[inc[q]] != serial) { stamp[inc[q]] = serial; ++nel; }
+        misfits += nel > elem_cap;
+      }
+    }
+    const double share = (double)misfits / (double)leaves, room = std::max(0.01, 0.04 * (leaf0 - L));
+    if (getenv("FEAHIP_NUMBERING_VERBOSE")) fprintf(stderr, "rcb leaf %d: %.1f %% of the sampled leaves do not fit (%.0f %% allowed)\n", L, 100 * share, 100 * room);
+    if (share <= room) return L;
+  }
+  return leaf0 / 2;
 }
 }  // namespace
 
@@ -83,6 +203,7 @@ bool locality_numbering(int N, int E, int npe, const int *conn, const double *X 
   // USE (nine in ten between the first and the last hold a node: a lattice fits any finer grid as well); the finest
   // that counts wins.  An exact lattice returns itself, a TetGen mesh keeps the median spacing and the box corner.
   double lat_o[3] = {lo[0], lo[1], lo[2]};
+  int fitted = 0;                                             // axes whose nodes sit on the planes of a lattice
   for (int k = 0; k < 3; ++k) {
     double cand[3] = {h[k], 0.0, 0.0};
     {
@@ -127,7 +248,30 @@ bool locality_numbering(int N, int E, int npe, const int *conn, const double *X 
       for (char u : used) nused += u;
       if (std::sqrt(ss / (double)N) < 0.2 && 10 * nused >= 9 * (q1 - q0 + 1) && (best_h == 0.0 || hh < best_h)) { best_h = hh; best_o = o + hh * (double)q0; }
     }
-    if (best_h > 0.0) { h[k] = best_h; lat_o[k] = best_o; }
+    if (best_h > 0.0) { h[k] = best_h; lat_o[k] = best_o; ++fitted; }
+  }
+  if (fitted == 0) {                                          // no lattice on any axis: bisection instead of cells
+    const char *e = getenv("FEAHIP_NUMBERING_RCB");
+    if (!(e && atoi(e) == 0)) {
+      std::vector<int> order((size_t)N);
+      for (int a = 0; a < N; ++a) order[a] = a;
+      // leaves: the rows of a chunk (64 for 4-node and 8-node elements; 64 measured best for the 10-node elements of
+      // the reference's TetGen deck too: 2.77 evaluations per element against 2.90 with 48 and 3.03 with the cells),
+      // fewer where 4-node elements are dense (rcb_pick_leaf)
+      int leaf = FEA_G_MAX_ROWS;
+      const char *w = getenv("FEAHIP_NUMBERING_RCB_LEAF");
+      if (w) leaf = std::max(8, atoi(w));
+      rcb_order(X, order.data(), N, leaf);
+      if (npe == 4 && !w) {
+        const int pick = rcb_pick_leaf(N, E, conn, X, order.data(), leaf, FEA_G_ELEMS_TARGET);
+        if (pick != leaf) {
+          for (int a = 0; a < N; ++a) order[a] = a;
+          rcb_order(X, order.data(), N, pick);
+        }
+      }
+      for (int r = 0; r < N; ++r) new_of_old[order[r]] = r;
+      return true;
+    }
   }
   int cn[3];                                                  // nodes of a cell along x, y, z
   cn[a_fast] = cell[0]; cn[a_slow] = cell[1]; cn[a_mid] = cell[2];

@@ -74,6 +74,7 @@ ABI = {
     "feahip_sync": [C.c_void_p],
     "feahip_time_kernel": [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp],
     "feahip_sizes": [C.c_void_p, C.POINTER(C.c_longlong)],
+    "feahip_host_gather_stats": [C.c_int, C.c_int, C.c_int, _ip, C.POINTER(C.c_longlong), _ip],
     "feahip_host_assembly_digest": [C.c_int, C.c_int, C.c_int, _ip, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), _ip],
     "feahip_assembly_in_use": [C.c_void_p, _ip],
     "feahip_node_numbering": [C.c_void_p, _ip],
@@ -542,6 +543,19 @@ def host_numbering(elements, nodes):
     if rc < 0:
         raise FeaHipError(f"feahip_host_numbering failed ({rc})")
     return out, bool(rc)
+
+
+def host_gather_stats(elements, n_nodes):
+    """Shape of the GATHER maps of a mesh (4-, 10- or 8-node elements) in the numbering given (host only): dict + chunks by row count."""
+    el = np.ascontiguousarray(elements, dtype=np.int32)
+    st = np.zeros(6, dtype=np.int64)
+    hist = np.zeros(65, dtype=np.int32)
+    rc = load_library().feahip_host_gather_stats(n_nodes, el.shape[0], el.shape[1], _i(el), st.ctypes.data_as(C.POINTER(C.c_longlong)), _i(hist))
+    if rc:
+        raise FeaHipError(f"feahip_host_gather_stats failed ({rc})")
+    return {"chunks": int(st[0]), "evals": int(st[1]), "elements": int(st[2]), "rows": int(st[3]),
+            "evals_per_element": float(st[1]) / float(st[2]), "rows_per_chunk": float(st[3]) / float(st[0]),
+            "chunks_with_predecessors_words": int(st[4]), "map_bytes": int(st[5])}, hist
 
 
 def host_assembly_digest(elements, n_nodes, rank=0, nranks=1):

@@ -245,12 +245,23 @@ int feahip_shard_plan(int n_nodes, int n_elems, int npe, const int *elements, in
 int feahip_host_assembly_digest(int n_nodes, int n_elems, int npe, const int *elements, int rank, int nranks,
                                 unsigned long long *rowhash, int *rows);
 
+/* Host-only (no device): shape of the GATHER maps (npe = 4, 10 or 8) for a
+ * mesh in the numbering it is given (pass library ids to see what a context
+ * builds): stats[6] = {chunks, element evaluations, distinct elements, rows,
+ * chunks repeating their predecessor's map words, map bytes};
+ * rows_hist[65] (may be null) = chunks by row count.  An element is evaluated
+ * once per chunk that owns one of its nodes (fea_solver.c:887-1068 visits each
+ * element once): evaluations / distinct elements is what a numbering costs.  */
+int feahip_host_gather_stats(int n_nodes, int n_elems, int npe, const int *elements,
+                             long long *stats, int *rows_hist);
+
 /* ---- node numbering ---------------------------------------------------- */
 /* The reference keeps the nodes in deck order (sexp_loader.c:170-215) and its
  * dof index is node * 3 + axis (fea_solver.c:377-384).  The kernels here own
  * runs of consecutive block rows, so feahip_create numbers the nodes itself
  * (compact cells of 4 x 4 x 4 nodes (48 half-grid nodes for 10-node elements), cells in slabs across the longest axis;
- * csrc/renumber.cpp) and works in that numbering.  Every entry of this header
+ * a mesh that sits on no lattice: recursive coordinate bisection into leaves of up to 64 nodes, the first cuts
+ * across the longest axis; csrc/renumber.cpp) and works in that numbering.  Every entry of this header
  * that takes or returns node-indexed data translates: the caller passes and
  * receives its OWN node ids and dof indices, bit-exactly -- elements,
  * prescribed node ids, coordinates, forces, solution, the Yale matrix (rows,

@@ -74,6 +74,39 @@ def test_unstructured_deck_gets_a_permutation_of_compact_cells(decks_dir, tmp_pa
     assert y[: len(y) // 8].max() < y[-len(y) // 8:].min()
 
 
+def test_unstructured_mesh_is_bisected_into_leaves_the_chunks_follow(decks_dir, tmp_path, monkeypatch):
+    """A mesh whose nodes sit on no lattice (the corner tetrahedra of the reference's TetGen deck, 2 x 2 x 1 copies) is
+    numbered by recursive coordinate bisection: against the bucket sort into cells (FEAHIP_NUMBERING_RCB=0) the gather
+    maps come out with fewer, longer chunks and fewer element evaluations per element; both numberings are bijections
+    and the digest of what the maps say per row, taken back to the caller's ids, does not depend on the numbering's
+    cut (every (row, column, element) contribution is listed once either way: the per-row counts agree)."""
+    p = tmp_path / "brick_fine.sexp"
+    with gzip.open(os.path.join(decks_dir, "brick_fine.sexp.gz"), "rb") as src, open(p, "wb") as dst:
+        shutil.copyfileobj(src, dst)
+    lin = mesh.tiled(mesh.corner_tets(feahip.Deck.load(str(p))), (2, 2, 1))
+    N = len(lin.nodes)
+    perm, renumbered = feahip.host_numbering(lin.elements, lin.nodes)
+    assert renumbered and np.array_equal(np.sort(perm), np.arange(N))
+    st, hist = feahip.host_gather_stats(perm[lin.elements], N)
+    assert hist.sum() == st["chunks"] and (hist * np.arange(65)).sum() == N
+    monkeypatch.setenv("FEAHIP_NUMBERING_RCB", "0")
+    perm_c, _ = feahip.host_numbering(lin.elements, lin.nodes)
+    st_c, _ = feahip.host_gather_stats(perm_c[lin.elements], N)
+    monkeypatch.delenv("FEAHIP_NUMBERING_RCB")
+    assert np.array_equal(np.sort(perm_c), np.arange(N)) and not np.array_equal(perm, perm_c)
+    assert st["elements"] == st_c["elements"] == len(lin.elements)
+    assert st["chunks"] < 0.93 * st_c["chunks"], (st, st_c)
+    assert st["evals_per_element"] < st_c["evals_per_element"], (st, st_c)
+    assert st["rows_per_chunk"] > 56.0, st
+    # deterministic, and independent of the order the caller's nodes come in
+    rng = np.random.default_rng(5)
+    shuffle = rng.permutation(N)                      # caller id a -> shuffle[a]
+    nodes2 = np.empty_like(lin.nodes); nodes2[shuffle] = lin.nodes
+    perm2, _ = feahip.host_numbering(shuffle[lin.elements].astype(np.int32), nodes2)
+    order, order2 = np.argsort(perm), np.argsort(perm2)
+    assert np.array_equal(lin.nodes[order], nodes2[order2])     # the same points in the same library order
+
+
 def test_shard_ranges_are_slabs_of_the_library_numbering():
     """What the row shard cuts are ranges of LIBRARY ids: the host-only plan of the mesh as the library numbers it
     owns contiguous y-slabs of a lexicographically numbered bar."""

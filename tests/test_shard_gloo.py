@@ -140,7 +140,16 @@ def _worker(rank, world, port, quadratic, result_dir):
 @pytest.mark.parametrize("quadratic", [False, True])
 def test_two_rank_halo_plan_and_cg(tmp_path, quadratic):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), quadratic, str(tmp_path)), nprocs=world, join=True)
+    # the port is free when it is chosen, not necessarily when rank 0 binds it: a failed RENDEZVOUS gets one more port
+    for attempt in range(2):
+        try:
+            mp.spawn(_worker, args=(world, _free_port(), quadratic, str(tmp_path)), nprocs=world, join=True)
+            break
+        except Exception as exc:
+            rendezvous = any(w in str(exc) for w in ("EADDRINUSE", "address already in use", "Address already in use",
+                                                     "DistNetworkError", "DistStoreError", "Connection reset"))
+            if attempt == 1 or not rendezvous:
+                raise
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
 
 
