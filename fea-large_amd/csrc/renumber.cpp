@@ -251,19 +251,23 @@ bool locality_numbering(int N, int E, int npe, const int *conn, const double *X 
     if (best_h > 0.0) { h[k] = best_h; lat_o[k] = best_o; ++fitted; }
   }
   if (fitted == 0) {                                          // no lattice on any axis: bisection instead of cells
+    // 4-node tetrahedra by default (the corner tetrahedra of the reference's TetGen deck at 10M elements: 0.950 ->
+    // 0.838 ms per assembly, gpurun_out/r4_h2); 10-node and 8-node elements only on request: their chunks are bounded
+    // by elements (127), not rows, and the deck's own 10-node mesh came out even (3.03 -> 2.94 evaluations per
+    // element, 31 964 -> 32 539 chunks, 2.345 -> 2.365 ms)
     const char *e = getenv("FEAHIP_NUMBERING_RCB");
-    if (!(e && atoi(e) == 0)) {
+    if (e ? atoi(e) != 0 : npe == 4) {
       std::vector<int> order((size_t)N);
       for (int a = 0; a < N; ++a) order[a] = a;
-      // leaves: the rows of a chunk (64 for 4-node and 8-node elements; 64 measured best for the 10-node elements of
-      // the reference's TetGen deck too: 2.77 evaluations per element against 2.90 with 48 and 3.03 with the cells),
-      // fewer where 4-node elements are dense (rcb_pick_leaf)
+      // leaves: the rows of a chunk, fewer where 4-node elements are dense (rcb_pick_leaf)
       int leaf = FEA_G_MAX_ROWS;
       const char *w = getenv("FEAHIP_NUMBERING_RCB_LEAF");
       if (w) leaf = std::max(8, atoi(w));
       rcb_order(X, order.data(), N, leaf);
       if (npe == 4 && !w) {
-        const int pick = rcb_pick_leaf(N, E, conn, X, order.data(), leaf, FEA_G_ELEMS_TARGET);
+        int cap = FEA_G_ELEMS_TARGET;                          // the limit pass A works with (gather.cpp)
+        if (const char *g = getenv("FEAHIP_GATHER_ELEMS")) cap = std::max(8, std::min(FEA_G_MAX_ELEMS, atoi(g)));
+        const int pick = rcb_pick_leaf(N, E, conn, X, order.data(), leaf, cap);
         if (pick != leaf) {
           for (int a = 0; a < N; ++a) order[a] = a;
           rcb_order(X, order.data(), N, pick);
