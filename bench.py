@@ -49,7 +49,7 @@ def pmc_traffic(args, world, kernel):
     number is the one measured for THIS kernel and configuration (profiles/pmc_traffic.json carries the kernel, the
     numbering and the commit it was measured at), and null for anything else.  Returns (bytes, provenance)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if world != 1 or args.n != 66 or args.quadratic or args.model != "neohookean" or not os.path.exists(path):
+    if world != 1 or args.n != 66 or args.quadratic or args.model != "neohookean" or args.mesh != "block" or not os.path.exists(path):
         return None, None
     try:
         rec = json.load(open(path))
@@ -59,6 +59,22 @@ def pmc_traffic(args, world, kernel):
         return rec["assembly_bytes_per_launch"], {k: rec.get(k) for k in ("commit", "source", "fetch_correction", "code_sha256")}
     except Exception:                               # noqa: BLE001
         return None, None
+
+
+def tetgen_corner_tets(feahip, mesh, copies=(8, 8, 7)):
+    """The unstructured linear-tet mesh of the off-lattice legs: the tetrahedra on the corner nodes of the reference's
+    TetGen deck brick_fine.sexp (deck order kept, sexp_loader.c:170-215), `copies` translated copies side by side."""
+    import gzip
+    import shutil
+    import tempfile
+    src = os.path.join(ROOT, "tests", "golden", "decks", "brick_fine.sexp.gz")
+    with tempfile.TemporaryDirectory() as td:
+        pth = os.path.join(td, "brick_fine.sexp")
+        with gzip.open(src, "rb") as fi, open(pth, "wb") as fo:
+            shutil.copyfileobj(fi, fo)
+        bf = feahip.Deck.load(pth)
+    bf.presc_node = (bf.presc_node - 1).astype(np.int32)         # the deck's boundary ids are 1-based (SURVEY.md 0)
+    return mesh.tiled(mesh.corner_tets(bf), copies)
 
 
 def kernel_code_hash():
@@ -225,9 +241,15 @@ def main():
                     "--quadratic), or bx,by,bz")
     ap.add_argument("--cpu-single-only", action="store_true", help="skip the one-oracle-copy-per-core CPU baseline")
     ap.add_argument("--no-tet10", action="store_true", help="skip the small TET10 leg of extras")
+    ap.add_argument("--mesh", default="block", choices=["block", "tetgen"],
+                    help="tetgen: the unstructured linear-tet mesh of the third off-lattice leg (corner tetrahedra of the reference's "
+                         "TetGen deck, 8 x 8 x 7 copies) as THE workload, assembly only -- for rocprofv3 / PMC passes of that case")
     ap.add_argument("--no-off-lattice", action="store_true", help="skip the off-lattice legs of extras (jittered + permuted block, tiled TetGen deck)")
     ap.add_argument("--pcg-variant", type=int, default=-1, help="-1: the context's default; 0: two-reduction PCG; 1: single-reduction PCG")
     args = ap.parse_args()
+    if args.mesh == "tetgen":                       # assembly of that mesh only: no solve, no other element, no CPU leg
+        args.no_newton = args.no_tet10 = args.no_off_lattice = True
+        args.cpu_sample = 0
     if args.cpu_sample is None:
         args.cpu_sample = 0 if args.hex else 14 if args.quadratic else 48     # (the CPU legs are wired for the tet blocks)
 
@@ -282,8 +304,14 @@ def main():
     # gather chunk of kernels_gather10.hip), 4x4x4 nodes for 8-node bricks
     brick = (None if args.numbering == "lex" else ((3, 4, 4) if args.quadratic else (4, 4, 4)) if args.numbering == "brick"
              else tuple(int(v) for v in args.numbering.split(",")))
-    deck = mesh.bar_deck(n=args.n, quadratic=args.quadratic, hexa=args.hex, recipe="clamped", model=model, brick=brick,
-                         solver_type=feahip.PCG_ILU, solver_tolerance=1e-14, solver_max_iter=20000)
+    if args.mesh == "tetgen":
+        if world > 1 or args.quadratic or args.hex:
+            print("bench.py: --mesh tetgen is a one-GPU linear-tet workload", file=sys.stderr)
+            sys.exit(2)
+        deck = tetgen_corner_tets(feahip, mesh)
+    else:
+        deck = mesh.bar_deck(n=args.n, quadratic=args.quadratic, hexa=args.hex, recipe="clamped", model=model, brick=brick,
+                             solver_type=feahip.PCG_ILU, solver_tolerance=1e-14, solver_max_iter=20000)
     free0 = torch.cuda.mem_get_info(local)[0]
     comm_ok = False
     if world > 1:
@@ -388,8 +416,9 @@ def main():
         "aux_map_bytes_per_element": sz["aux_bytes"] / E_total,
         "rccl_sharded_solve": comm_ok if world > 1 else None,
         "device_bytes_this_rank": int(dev_bytes),
-        "node_numbering": ("caller: " + ("lexicographic (x fastest, z, y slowest)" if brick is None else "bricks of %dx%dx%d nodes" % brick) +
-                           "; library: " + ("renumbered to compact cells (csrc/renumber.cpp)" if renumbered else "the caller's ids kept")),
+        "node_numbering": ("caller: " + ("deck order (TetGen), copy by copy" if args.mesh == "tetgen" else "lexicographic (x fastest, z, y slowest)" if brick is None else "bricks of %dx%dx%d nodes" % brick) +
+                           "; library: " + (("renumbered by recursive coordinate bisection (csrc/renumber.cpp)" if args.mesh == "tetgen" else
+                                             "renumbered to compact cells (csrc/renumber.cpp)") if renumbered else "the caller's ids kept")),
         "verified": verified,
         "gather_maps": solver.assembly_stats(),
         "copy_bandwidth_GBps": copy_gbps,
@@ -475,7 +504,7 @@ def main():
                 "the reference's TetGen deck brick_fine.sexp (22 934 TET10 / 5 GP, 34 070 nodes, deck order), 4 x 4 x 3 copies side by side")
             leg("brick_fine_corner_tets_tiled", mesh.tiled(mesh.corner_tets(bf), (8, 8, 7)),
                 "the linear tetrahedra on the corner nodes of the same TetGen deck (22 934 TET4 / 1 GP), 8 x 8 x 7 copies side by side: "
-                "an unstructured linear-tet mesh for the headline kernel")
+                "an unstructured linear-tet mesh for the headline kernel (library numbering: recursive coordinate bisection, csrc/renumber.cpp)")
         except Exception as e:                      # noqa: BLE001
             off["brick_fine_tiled"] = {"failed": str(e)}
     traffic, traffic_src = pmc_traffic(args, world, kernel)
@@ -488,9 +517,11 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"{E_total} {'HEX8/8GP' if args.hex else 'TET10/5GP' if args.quadratic else 'TET4/1GP'} {args.model} block "
-                               f"({args.n}x{6 * args.n}x{args.n} {'bricks' if args.hex else 'Kuhn cubes'} on the 1x6x1 bar), "
-                               f"stiffness+residual assembly, deformed state k1=1.1",
+        "config": {"workload": (f"{E_total} TET4/1GP unstructured mesh (corner tetrahedra of the reference's TetGen deck brick_fine.sexp, "
+                                f"8 x 8 x 7 copies, deck order), stiffness+residual assembly, deformed state k1=1.1" if args.mesh == "tetgen" else
+                                f"{E_total} {'HEX8/8GP' if args.hex else 'TET10/5GP' if args.quadratic else 'TET4/1GP'} {args.model} block "
+                                f"({args.n}x{6 * args.n}x{args.n} {'bricks' if args.hex else 'Kuhn cubes'} on the 1x6x1 bar), "
+                                f"stiffness+residual assembly, deformed state k1=1.1"),
                    "elements": E_total, "nodes": N, "scalar_nnz": nnz, "clock_ramp_launches_before_warmup": RAMP,
                    "sharding": f"{world} slab(s) across y; a rank holds only its slab (owned nodes, the elements around them, their halo, "
                                f"locally indexed); ghost elements recomputed, no collective in assembly"},
