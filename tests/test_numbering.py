@@ -168,6 +168,66 @@ def test_jittered_and_permuted_block_against_the_oracle():
 
 
 @pytest.mark.gpu
+def test_unstructured_linear_tets_against_the_oracle(decks_dir, tmp_path):
+    """A mesh with no lattice under it -- the linear tetrahedra on the corner nodes of the reference's TetGen deck
+    (22 934 TET4, deck order: sexp_loader.c:170-215), numbered by the library's coordinate bisection -- against the
+    oracle on the caller's (TetGen) ids: the gather kernel ran, the context's numbering is the host-only one, pattern
+    bit-exact, K / f / residual-only launch 1e-12, BC cancellation, the solved increment (residual 1e-12 in the oracle's
+    system); and over two in-process
+    ranks (slabs of bisection ids) every rank's rows equal the unsharded ones."""
+    p = tmp_path / "brick_fine.sexp"
+    with gzip.open(os.path.join(decks_dir, "brick_fine.sexp.gz"), "rb") as src, open(p, "wb") as dst:
+        shutil.copyfileobj(src, dst)
+    bf = feahip.Deck.load(str(p))
+    bf.presc_node = (bf.presc_node - 1).astype(np.int32)      # the deck's boundary ids are 1-based (SURVEY.md 0)
+    deck = mesh.corner_tets(bf)
+    x = mesh.deformed_state(deck.nodes)
+    s, o = feahip.FeaSolver(deck), OracleSolver(deck)
+    lib = s.node_numbering()
+    assert np.array_equal(lib, feahip.host_numbering(deck.elements, deck.nodes)[0])
+    assert not np.array_equal(lib, np.arange(len(deck.nodes)))
+    s.set_nodes(x); o.set_nodes(x)
+    o.update_state(); o.create_stiffness(); o.create_residual_forces()
+    s.create_stiffness_and_residual()
+    assert s.update_state() == 0
+    assert s.assembly_in_use() == feahip.ASM_GATHER
+    st = s.assembly_stats()
+    assert st["evals_per_element"] < 2.1 and len(deck.nodes) / st["chunks"] > 50.0, st
+    off, idx, val = s.matrix_yale(); f = s.forces()
+    assert np.array_equal(off, o.offsets()) and np.array_equal(idx, o.indexes())
+    assert rel(val, o.values()) < 1e-12 and rel(f, o.forces()) < 1e-12
+    s.create_residual_forces()
+    assert rel(s.forces(), o.forces()) < 1e-12
+    # two in-process ranks: slabs of library ids
+    row_node = np.repeat(np.arange(s.ndof), np.diff(off)) // 3
+    g = feahip.FeaGroup(deck, 2)
+    g.each("set_nodes", x); g.each("create_stiffness_and_residual")
+    seen = np.zeros(len(deck.nodes), dtype=int)
+    for nd, r in zip(g.nodes, g.ranks):
+        assert r.assembly_in_use() == feahip.ASM_GATHER
+        seen[nd] += 1
+        own = np.zeros(len(deck.nodes), dtype=bool); own[nd] = True
+        mine = own[row_node]
+        _, _, v = r.matrix_yale()
+        assert np.abs(v[mine] - val[mine]).max() < 4e-16 * np.abs(val).max()
+        assert np.all(v[~mine] == 0)
+        d = r.owned_dofs()
+        assert np.array_equal(r.forces()[d], f[d])
+    assert np.all(seen == 1)
+    g.close()
+    s.apply_prescribed_bc(0.0); o.apply_prescribed_bc(0.0)
+    _, _, val_bc = s.matrix_yale()
+    assert rel(val_bc, o.values()) < 1e-12 and rel(s.forces(), o.forces()) < 1e-12
+    # the solved increment against the ORACLE's matrix and right-hand side (its skyline factorisation is no match for
+    # TetGen ids: the residual of the device's solution in the oracle's system instead)
+    s.solve_slae(feahip.PCG_ILU, 1e-15, 20000)
+    K = sp.csr_matrix((o.values(), o.indexes(), o.offsets()), shape=(s.ndof, s.ndof))
+    u = s.solution()
+    assert np.linalg.norm(K @ u - o.forces()) < 1e-12 * np.linalg.norm(o.forces())
+    s.close(); o.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("model", [feahip.MODEL_COMPRESSIBLE_NEOHOOKEAN, feahip.MODEL_A5])
 def test_renumbered_context_speaks_the_callers_numbering(model):
     """Every node-indexed entry of the ABI on a mesh the library renumbers, against the oracle run on the caller's
