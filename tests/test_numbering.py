@@ -172,7 +172,7 @@ def test_unstructured_linear_tets_against_the_oracle(decks_dir, tmp_path):
     """A mesh with no lattice under it -- the linear tetrahedra on the corner nodes of the reference's TetGen deck
     (22 934 TET4, deck order: sexp_loader.c:170-215), numbered by the library's coordinate bisection -- against the
     oracle on the caller's (TetGen) ids: the gather kernel ran, the context's numbering is the host-only one, pattern
-    bit-exact, K / f / residual-only launch 1e-12, BC cancellation, the solved increment (residual 1e-12 in the oracle's
+    bit-exact, K / f / residual-only launch 1e-12, BC cancellation, the solved increment (residual 1e-11 in the oracle's
     system); and over two in-process
     ranks (slabs of bisection ids) every rank's rows equal the unsharded ones."""
     p = tmp_path / "brick_fine.sexp"
@@ -223,7 +223,7 @@ def test_unstructured_linear_tets_against_the_oracle(decks_dir, tmp_path):
     s.solve_slae(feahip.PCG_ILU, 1e-15, 20000)
     K = sp.csr_matrix((o.values(), o.indexes(), o.offsets()), shape=(s.ndof, s.ndof))
     u = s.solution()
-    assert np.linalg.norm(K @ u - o.forces()) < 1e-12 * np.linalg.norm(o.forces())
+    assert np.linalg.norm(K @ u - o.forces()) < 1e-11 * np.linalg.norm(o.forces())
     s.close(); o.close()
 
 
