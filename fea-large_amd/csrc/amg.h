@@ -76,6 +76,7 @@ struct AmgHierarchy {
   bool tail_blob = true;                 // (FEAHIP_AMG_TAIL_BLOB=0: every launch gathers them array by array)
   bool fused_post = false;               // post-smoothing product and update in one launch (FEAHIP_AMG_FUSED_POST=1; measured 1.6-2.5 % slower per CG iteration than the two launches)
   double *d_pw = nullptr;                // scratch for the power iteration
+  double *d_lam = nullptr;               // [64] squared norms of the levels' power iterations (read once per numeric setup)
   long long bytes = 0;
 };
 
