@@ -279,7 +279,11 @@ int launch_assemble_quad(feahip_ctx *c, bool doF);
 #define FEA_G_DIAG_LANES (FEA_G_THREADS - FEA_G_TASK_THREADS)
 #define FEA_G_SLOT_BITS 10            // record slot inside a contribution / visit entry: slot | la << 10 | lb << 12
 #define FEA_G_MAX_SLOTS 1024
-#define FEA_G_REGW 4                  // contribution words a block thread keeps in registers (2 entries each)
+#define FEA_G_REGW 6                  // contribution words a block thread keeps in registers (2 entries each).  A lattice needs 3 (six
+                                      // elements around an edge at most); on the reference's TetGen deck 92 % of the chunks have a list of
+                                      // 5 words and 4 % one of 6, and with 4 in registers the rest was fetched INSIDE the gather phase,
+                                      // one exposed HBM round trip per word (kernels_gather.hip); the words are loaded only up to the
+                                      // mesh's longest list (GatherLayout::max_depth), so a lattice issues no more loads than before
 struct GatherHeader {                // 64 bytes, first thing in a chunk record
   int r0, r1, b0, nb;                // rows [r0, r1), blocks [b0, b0+nb) of the CSR
   int nnode, nelem, noffd, depth;    // depth: contribution words per block thread

@@ -64,8 +64,10 @@ void build_host_gather(int N, int E, const int *conn, const HostPattern &hp, int
   (void)E;
   out.ok = false; out.nchunks = 0; out.blob.clear(); out.first_row.clear();
   if (row_lo < 0 || row_hi > N || row_lo >= row_hi) return;
-  // limits of one chunk; the element target keeps three workgroups' records in one CU's LDS
-  int max_rows = FEA_G_MAX_ROWS, max_elems = FEA_G_ELEMS_TARGET, alpha = 24;
+  // limits of one chunk: its rows, and the element records one CU's LDS holds (a lattice's bricks stop at the row
+  // limit with FEA_G_ELEMS_TARGET elements whatever the element limit is -- its partition is the same for 672 and 719,
+  // checked on the 31^3, 40^3 and 66^3 blocks; an unstructured mesh uses the room: 2-3 % fewer chunks)
+  int max_rows = FEA_G_MAX_ROWS, max_elems = FEA_G_BIG == 1 ? FEA_G_MAX_ELEMS : FEA_G_ELEMS_TARGET, alpha = 24;
   if (const char *e = getenv("FEAHIP_GATHER_ROWS")) max_rows = std::max(1, std::min(FEA_G_MAX_ROWS, atoi(e)));
   if (const char *e = getenv("FEAHIP_GATHER_ELEMS")) max_elems = std::max(8, std::min(FEA_G_MAX_ELEMS, atoi(e)));
   if (const char *e = getenv("FEAHIP_GATHER_ALPHA")) alpha = std::max(0, atoi(e));
@@ -666,8 +668,8 @@ extern "C" int feahip_host_assembly_digest(int n_nodes, int n_elems, int npe, co
 }
 
 // Host-only (no device): what the gather maps (4-node, or 10-node / 8-node) look like for a mesh in the numbering it is given --
-// stats[0..5] = chunks, element evaluations, distinct elements, rows, chunks repeating their predecessor's words, map
-// bytes; rows_hist[FEA_G_MAX_ROWS + 1] (may be null) = chunks by row count.  What the numbering of an unstructured mesh
+// stats[0..7] = chunks, element evaluations, distinct elements, rows, chunks repeating their predecessor's words, map
+// bytes, chunks with block lists / diagonal lists longer than a thread's registers hold (4-node only); rows_hist[FEA_G_MAX_ROWS + 1] (may be null) = chunks by row count.  What the numbering of an unstructured mesh
 // is judged by before a device sees it (tools/gather_stats.py).
 extern "C" int feahip_host_gather_stats(int n_nodes, int n_elems, int npe, const int *elements, long long *stats, int *rows_hist)
 {
@@ -677,6 +679,7 @@ extern "C" int feahip_host_gather_stats(int n_nodes, int n_elems, int npe, const
   int rc = build_host_pattern(n_nodes, n_elems, npe, elements, hp, err);
   if (rc) return rc;
   const std::vector<int> *first_row;
+  stats[6] = stats[7] = 0;
   HostGather hg;
   HostGather10 hq;
   if (npe == 4) {
@@ -684,6 +687,18 @@ extern "C" int feahip_host_gather_stats(int n_nodes, int n_elems, int npe, const
     if (!hg.ok) return FEAHIP_EINVAL;
     stats[0] = hg.nchunks; stats[1] = hg.total_evals; stats[2] = hg.distinct_elems;
     stats[4] = hg.same_as_previous; stats[5] = (long long)hg.blob.size();
+    for (int p = 0; p < hg.nchunks; ++p) {            // lists longer than the words a thread keeps in registers are walked out of memory
+      const GatherHeader &gh = *reinterpret_cast<const GatherHeader *>(hg.blob.data() + (size_t)p * hg.lay.stride);
+      stats[6] += gh.depth > FEA_G_REGW; stats[7] += gh.ddepth > FEA_G_REGW;
+    }
+    if (getenv("FEAHIP_NUMBERING_VERBOSE")) {         // chunks by the words of their longest block list / diagonal list
+      int hd[17] = {0}, hdd[17] = {0};
+      for (int p = 0; p < hg.nchunks; ++p) {
+        const GatherHeader &gh = *reinterpret_cast<const GatherHeader *>(hg.blob.data() + (size_t)p * hg.lay.stride);
+        ++hd[std::min(gh.depth, 16)]; ++hdd[std::min(gh.ddepth, 16)];
+      }
+      for (int k = 0; k <= 16; ++k) if (hd[k] || hdd[k]) fprintf(stderr, "gather maps: %d words: %d chunks by block list, %d by diagonal list\n", k, hd[k], hdd[k]);
+    }
     first_row = &hg.first_row;
   } else {
     build_host_gather10(n_nodes, n_elems, npe, elements, hp, 0, n_nodes, hq);

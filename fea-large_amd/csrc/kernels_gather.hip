@@ -84,7 +84,7 @@ void k_assemble_gather(GatherArgs A, int run_len)
   }
   // nothing is pending when the loop is entered: otherwise the loop header inherits "node1 may still be in
   // flight" and the compiler waits for everything (s_waitcnt vmcnt(0)) at the top of EVERY iteration
-  asm volatile("" : : "v"(mn.eids), "v"(mn.tpos), "v"(mn.cw[0]), "v"(mn.cw[1]), "v"(mn.cw[2]), "v"(mn.cw[3]),
+  asm volatile("" : : "v"(mn.eids), "v"(mn.tpos), "v"(mn.cw[0]), "v"(mn.cw[1]), "v"(mn.cw[2]), "v"(mn.cw[3]), "v"(mn.cw[4]), "v"(mn.cw[5]),
                "v"(mn.vw[0]), "v"(mn.vw[1]), "v"(mn.kd), "v"(mn.vb), "v"(mn.ve), "v"(node1), "v"(gauss_w));
   G_BARRIER();
 
@@ -182,7 +182,7 @@ void k_assemble_gather(GatherArgs A, int run_len)
 #pragma unroll
       for (int k = 0; k < FEA_G_REGW; ++k)
         if (k < wd) { { const GRead r = G_FETCH(m.cw[k] & 0xFFFFu); G_APPLY(r); } { const GRead r = G_FETCH(m.cw[k] >> 16); G_APPLY(r); } }
-      for (int k = FEA_G_REGW; k < wd; ++k) {               // blocks with more than 8 contributions (unstructured meshes)
+      for (int k = FEA_G_REGW; k < wd; ++k) {               // blocks with more than 12 contributions
         const unsigned w = reinterpret_cast<const unsigned *>(rec + A.lay.o_clist)[k * FEA_G_THREADS + t];
         g_consume(sT, w & 0xFFFFu, acc, accd); g_consume(sT, w >> 16, acc, accd);
       }
@@ -194,7 +194,7 @@ void k_assemble_gather(GatherArgs A, int run_len)
 #pragma unroll
       for (int k = 0; k < FEA_G_REGW; ++k)
         if (k < h.ddepth) { g_consume_diag<DOF>(sT, m.cw[k] & 0xFFFFu, dg, fa); g_consume_diag<DOF>(sT, m.cw[k] >> 16, dg, fa); }
-      for (int k = FEA_G_REGW; k < h.ddepth; ++k) {        // nodes with more than 32 elements around them
+      for (int k = FEA_G_REGW; k < h.ddepth; ++k) {        // nodes with more than 48 elements around them
         const unsigned w = reinterpret_cast<const unsigned *>(rec + A.lay.o_dlist)[k * FEA_G_DIAG_LANES + t - G_TASK_THREADS];
         g_consume_diag<DOF>(sT, w & 0xFFFFu, dg, fa); g_consume_diag<DOF>(sT, w >> 16, dg, fa);
       }
@@ -248,7 +248,7 @@ void k_assemble_gather(GatherArgs A, int run_len)
     // prefetches themselves are younger, they were requested a state + gather phase ago, and nothing ever waits
     // for a store.
     G_STAMP(4);
-    asm volatile("" : : "v"(mn.eids), "v"(mn.tpos), "v"(mn.cw[0]), "v"(mn.cw[1]), "v"(mn.cw[2]), "v"(mn.cw[3]),
+    asm volatile("" : : "v"(mn.eids), "v"(mn.tpos), "v"(mn.cw[0]), "v"(mn.cw[1]), "v"(mn.cw[2]), "v"(mn.cw[3]), "v"(mn.cw[4]), "v"(mn.cw[5]),
                  "v"(mn.vw[0]), "v"(mn.vw[1]), "v"(mn.kd), "v"(mn.vb), "v"(mn.ve), "v"(node1), "v"(hword));
     if (more && node_lane) {                           // next chunk's coordinates: the tile has been dead since the state phase
       sC[t * 3] = ca0; sC[t * 3 + 1] = make_double2(ca1.x, cc0.x); sC[t * 3 + 2] = make_double2(cc0.y, cc1.x);

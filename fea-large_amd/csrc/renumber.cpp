@@ -101,23 +101,24 @@ void rcb_order(const double *X, int *idx, int n, int leaf)
 }
 
 // The leaf size for 4-node tetrahedra.  A chunk is bounded in ELEMENTS as well as rows (the records of the elements around
-// its rows fill the LDS: FEA_G_ELEMS_TARGET), and where a mesh is dense (the inside of the reference's TetGen deck: ~750
-// elements around 64 nodes, ~450 at its faces) a leaf of 64 does not fit: pass A cuts it into 52 + 12 rows, and the 10M
-// mesh ends with 53 rows per chunk.  A leaf a few rows SHORT of the row limit leaves pass A room to move a boundary: a
-// leaf that is too dense hands its last rows to its neighbour.  Measured on that deck (chunks against leaves, pass A's
-// own partition): leaves of 56-59 all end as one chunk, of 60 +0.4 %, 61 +2.5 %, 62 +10 %, 64 +20 % -- 60 is the
-// best there (34 325 chunks of 60 rows and 1.75 evaluations per element on the 10M mesh, where the cells gave 41 393
-// of 50 and 1.90).  The rule that picks it: after one bisection with leaves of 64, a few blocks of 8 192 consecutive
-// ids (compact regions: unions of subtrees) spread over the id range are bisected again with every even candidate size
-// L and the elements around every leaf are counted; the largest L whose share of leaves that do not fit is within what
-// 64 - L rows of room absorb (4 % per row: 62 -> 8 %, 60 -> 16 %; 1 % for 64 itself) wins.  Measured and dropped:
+// its rows fill the LDS: FEA_G_MAX_ELEMS), and where a mesh is dense (the inside of the reference's TetGen deck: ~750
+// elements around 64 nodes, ~450 at its faces) a leaf of 64 does not fit: pass A (gather.cpp) cuts it into 52 + 12
+// rows, and the 10M mesh ends with 53 rows per chunk.  A leaf a few rows SHORT of the row limit leaves pass A room to
+// move a boundary: a leaf that is too dense hands its last rows to its neighbour.  How short is decided by pass A
+// itself: after one bisection with leaves of 64, two blocks of 8 192 consecutive ids (compact regions: unions of
+// subtrees, at one and two thirds of the id range) are bisected again with every candidate size, cut out as
+// sub-meshes (their nodes first, the nodes of the elements around them behind) and handed to the pattern and gather
+// builders; the size with the fewest chunks over both blocks wins, ties to the fewer element evaluations.  On the
+// TetGen deck's corner tetrahedra, 10M elements (gpurun_out/r4_h6): leaves of 60 give 34 325 chunks and 0.851 ms,
+// of 62 33 217 and 0.835, of 63 32 690 and 0.830; the cells gave 41 393 and 0.950.  Measured and dropped on the way:
 // leaves bounded by the element incidences of their nodes (a weight limit in the bisection: the incidences predict
 // the distinct elements too loosely); the prefixes of the 64-leaves as a model of shorter leaves (a prefix is half +
-// quarter + ... of a leaf, a slab, not a cube); a greedy walk as a model of pass A (it cuts 60.7 rows whatever the leaf).
-int rcb_pick_leaf(int N, int E, const int *conn, const double *X, const int *order, int leaf0, int elem_cap)
+// quarter + ... of a leaf, a slab, not a cube); a greedy walk as a model of pass A (it cuts 60.7 rows whatever the
+// leaf); the share of leaves whose elements do not fit against the rows of room (it picks 60 where 63 is better).
+int rcb_pick_leaf(int N, int E, const int *conn, const double *X, const int *order, int leaf0)
 {
   const int block = 8192;
-  if (N < 4 * leaf0) return leaf0;
+  if (N < 4 * block) return leaf0;                             // small meshes: the row limit itself
   std::vector<int> incptr((size_t)N + 1, 0);
   for (size_t q = 0; q < (size_t)E * 4; ++q) ++incptr[(size_t)conn[q] + 1];
   for (int a = 0; a < N; ++a) incptr[(size_t)a + 1] += incptr[a];
@@ -125,30 +126,54 @@ int rcb_pick_leaf(int N, int E, const int *conn, const double *X, const int *ord
   for (int e = 0; e < E; ++e)
     for (int k = 0; k < 4; ++k) inc[(size_t)fill[conn[(size_t)e * 4 + k]]++] = e;
   std::vector<int>().swap(fill);
-  const int nblocks = std::max(1, std::min(8, N / block)), blen = std::min(N, block);
-  std::vector<int> stamp((size_t)E, -1), ids((size_t)blen);
-  int serial = 0;
-  for (int L = leaf0; L >= leaf0 / 2; L -= 2) {
-    long long leaves = 0, misfits = 0;
-    for (int b = 0; b < nblocks; ++b) {
-      const int start = nblocks == 1 ? 0 : (int)((long long)(N - blen) * b / (nblocks - 1));
-      for (int i = 0; i < blen; ++i) ids[i] = order[(size_t)start + i];
-      std::sort(ids.begin(), ids.end());                        // the result must not depend on the order the block came in
-      rcb_order(X, ids.data(), blen, L);
-      for (int l0 = 0; l0 < blen; l0 += L, ++serial, ++leaves) {
-        const int l1 = std::min(blen, l0 + L);
-        int nel = 0;
-        for (int i = l0; i < l1; ++i)
-          for (int q = incptr[ids[i]]; q < incptr[ids[i] + 1]; ++q)
-            if (stamp[inc[q]] != serial) { stamp[inc[q]] = serial; ++nel; }
-        misfits += nel > elem_cap;
+  const int cand[] = {64, 63, 62, 61, 60, 58, 56, 52, 48};
+  const int ncand = (int)(sizeof(cand) / sizeof(cand[0]));
+  std::vector<long long> chunks((size_t)ncand, 0), evals((size_t)ncand, 0);
+  std::vector<char> failed((size_t)ncand, 0);
+  std::vector<std::thread> th;
+  for (int ci = 0; ci < ncand; ++ci)
+    th.emplace_back([&, ci] {
+      const int L = cand[ci];
+      if (L > leaf0) { failed[ci] = 1; return; }
+      std::vector<int> ids((size_t)block), local((size_t)N, -1), estamp((size_t)E, -1), lconn, touched;
+      for (int b = 1; b <= 2; ++b) {
+        const int start = (int)((long long)(N - block) * b / 3);
+        for (int i = 0; i < block; ++i) ids[i] = order[(size_t)start + i];
+        std::sort(ids.begin(), ids.end());                      // the result must not depend on the order the block came in
+        rcb_order(X, ids.data(), block, L);
+        // the block as a sub-mesh: its nodes first in the new order, the other nodes of the elements around them behind
+        touched.clear(); lconn.clear();
+        int nloc = block;
+        for (int i = 0; i < block; ++i) { local[ids[i]] = i; touched.push_back(ids[i]); }
+        for (int i = 0; i < block; ++i)
+          for (int q = incptr[ids[i]]; q < incptr[ids[i] + 1]; ++q) {
+            const int e = inc[q];
+            if (estamp[e] == b) continue;
+            estamp[e] = b;
+            for (int k = 0; k < 4; ++k) {
+              const int g = conn[(size_t)e * 4 + k];
+              if (local[g] < 0) { local[g] = nloc++; touched.push_back(g); }
+              lconn.push_back(local[g]);
+            }
+          }
+        HostPattern hp;
+        HostGather hg;
+        std::string err;
+        if (build_host_pattern(nloc, (int)(lconn.size() / 4), 4, lconn.data(), hp, err) == 0)
+          build_host_gather(nloc, (int)(lconn.size() / 4), lconn.data(), hp, 0, block, hg);
+        for (int g : touched) local[g] = -1;
+        if (!hg.ok) { failed[ci] = 1; return; }
+        chunks[ci] += hg.nchunks; evals[ci] += hg.total_evals;
       }
-    }
-    const double share = (double)misfits / (double)leaves, room = std::max(0.01, 0.04 * (leaf0 - L));
-    if (getenv("FEAHIP_NUMBERING_VERBOSE")) fprintf(stderr, "rcb leaf %d: %.1f %% of the sampled leaves do not fit (%.0f %% allowed)\n", L, 100 * share, 100 * room);
-    if (share <= room) return L;
+    });
+  for (auto &x : th) x.join();
+  int best = -1;
+  for (int ci = 0; ci < ncand; ++ci) {
+    if (failed[ci]) continue;
+    if (getenv("FEAHIP_NUMBERING_VERBOSE")) fprintf(stderr, "rcb leaf %d: %lld chunks, %lld evaluations on the sample blocks\n", cand[ci], chunks[ci], evals[ci]);
+    if (best < 0 || chunks[ci] < chunks[best] || (chunks[ci] == chunks[best] && evals[ci] < evals[best])) best = ci;
   }
-  return leaf0 / 2;
+  return best < 0 ? leaf0 : cand[best];
 }
 }  // namespace
 
@@ -265,9 +290,7 @@ bool locality_numbering(int N, int E, int npe, const int *conn, const double *X 
       if (w) leaf = std::max(8, atoi(w));
       rcb_order(X, order.data(), N, leaf);
       if (npe == 4 && !w) {
-        int cap = FEA_G_ELEMS_TARGET;                          // the limit pass A works with (gather.cpp)
-        if (const char *g = getenv("FEAHIP_GATHER_ELEMS")) cap = std::max(8, std::min(FEA_G_MAX_ELEMS, atoi(g)));
-        const int pick = rcb_pick_leaf(N, E, conn, X, order.data(), leaf, cap);
+        const int pick = rcb_pick_leaf(N, E, conn, X, order.data(), leaf);
         if (pick != leaf) {
           for (int a = 0; a < N; ++a) order[a] = a;
           rcb_order(X, order.data(), N, pick);

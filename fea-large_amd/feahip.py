@@ -548,14 +548,15 @@ def host_numbering(elements, nodes):
 def host_gather_stats(elements, n_nodes):
     """Shape of the GATHER maps of a mesh (4-, 10- or 8-node elements) in the numbering given (host only): dict + chunks by row count."""
     el = np.ascontiguousarray(elements, dtype=np.int32)
-    st = np.zeros(6, dtype=np.int64)
+    st = np.zeros(8, dtype=np.int64)
     hist = np.zeros(65, dtype=np.int32)
     rc = load_library().feahip_host_gather_stats(n_nodes, el.shape[0], el.shape[1], _i(el), st.ctypes.data_as(C.POINTER(C.c_longlong)), _i(hist))
     if rc:
         raise FeaHipError(f"feahip_host_gather_stats failed ({rc})")
     return {"chunks": int(st[0]), "evals": int(st[1]), "elements": int(st[2]), "rows": int(st[3]),
             "evals_per_element": float(st[1]) / float(st[2]), "rows_per_chunk": float(st[3]) / float(st[0]),
-            "chunks_with_predecessors_words": int(st[4]), "map_bytes": int(st[5])}, hist
+            "chunks_with_predecessors_words": int(st[4]), "map_bytes": int(st[5]),
+            "chunks_with_long_block_lists": int(st[6]), "chunks_with_long_diagonal_lists": int(st[7])}, hist
 
 
 def host_assembly_digest(elements, n_nodes, rank=0, nranks=1):

@@ -247,8 +247,9 @@ int feahip_host_assembly_digest(int n_nodes, int n_elems, int npe, const int *el
 
 /* Host-only (no device): shape of the GATHER maps (npe = 4, 10 or 8) for a
  * mesh in the numbering it is given (pass library ids to see what a context
- * builds): stats[6] = {chunks, element evaluations, distinct elements, rows,
- * chunks repeating their predecessor's map words, map bytes};
+ * builds): stats[8] = {chunks, element evaluations, distinct elements, rows,
+ * chunks repeating their predecessor's map words, map bytes, chunks with a
+ * block list / a diagonal list longer than a thread keeps in registers};
  * rows_hist[65] (may be null) = chunks by row count.  An element is evaluated
  * once per chunk that owns one of its nodes (fea_solver.c:887-1068 visits each
  * element once): evaluations / distinct elements is what a numbering costs.  */
