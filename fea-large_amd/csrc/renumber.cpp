@@ -131,39 +131,42 @@ int rcb_pick_leaf(int N, int E, const int *conn, const double *X, const int *ord
   std::vector<long long> chunks((size_t)ncand, 0), evals((size_t)ncand, 0);
   std::vector<char> failed((size_t)ncand, 0);
   std::vector<std::thread> th;
-  for (int ci = 0; ci < ncand; ++ci)
-    th.emplace_back([&, ci] {
-      const int L = cand[ci];
-      if (L > leaf0) { failed[ci] = 1; return; }
+  const int nt = 3;                                            // each keeps an [N] and an [E] scratch array
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&, t] {
       std::vector<int> ids((size_t)block), local((size_t)N, -1), estamp((size_t)E, -1), lconn, touched;
-      for (int b = 1; b <= 2; ++b) {
-        const int start = (int)((long long)(N - block) * b / 3);
-        for (int i = 0; i < block; ++i) ids[i] = order[(size_t)start + i];
-        std::sort(ids.begin(), ids.end());                      // the result must not depend on the order the block came in
-        rcb_order(X, ids.data(), block, L);
-        // the block as a sub-mesh: its nodes first in the new order, the other nodes of the elements around them behind
-        touched.clear(); lconn.clear();
-        int nloc = block;
-        for (int i = 0; i < block; ++i) { local[ids[i]] = i; touched.push_back(ids[i]); }
-        for (int i = 0; i < block; ++i)
-          for (int q = incptr[ids[i]]; q < incptr[ids[i] + 1]; ++q) {
-            const int e = inc[q];
-            if (estamp[e] == b) continue;
-            estamp[e] = b;
-            for (int k = 0; k < 4; ++k) {
-              const int g = conn[(size_t)e * 4 + k];
-              if (local[g] < 0) { local[g] = nloc++; touched.push_back(g); }
-              lconn.push_back(local[g]);
+      for (int ci = t; ci < ncand; ci += nt) {
+        const int L = cand[ci];
+        if (L > leaf0) { failed[ci] = 1; continue; }
+        for (int b = 1; b <= 2 && !failed[ci]; ++b) {
+          const int start = (int)((long long)(N - block) * b / 3), stamp = ci * 4 + b;
+          for (int i = 0; i < block; ++i) ids[i] = order[(size_t)start + i];
+          std::sort(ids.begin(), ids.end());                    // the result must not depend on the order the block came in
+          rcb_order(X, ids.data(), block, L);
+          // the block as a sub-mesh: its nodes first in the new order, the other nodes of the elements around them behind
+          touched.clear(); lconn.clear();
+          int nloc = block;
+          for (int i = 0; i < block; ++i) { local[ids[i]] = i; touched.push_back(ids[i]); }
+          for (int i = 0; i < block; ++i)
+            for (int q = incptr[ids[i]]; q < incptr[ids[i] + 1]; ++q) {
+              const int e = inc[q];
+              if (estamp[e] == stamp) continue;
+              estamp[e] = stamp;
+              for (int k = 0; k < 4; ++k) {
+                const int g = conn[(size_t)e * 4 + k];
+                if (local[g] < 0) { local[g] = nloc++; touched.push_back(g); }
+                lconn.push_back(local[g]);
+              }
             }
-          }
-        HostPattern hp;
-        HostGather hg;
-        std::string err;
-        if (build_host_pattern(nloc, (int)(lconn.size() / 4), 4, lconn.data(), hp, err) == 0)
-          build_host_gather(nloc, (int)(lconn.size() / 4), lconn.data(), hp, 0, block, hg);
-        for (int g : touched) local[g] = -1;
-        if (!hg.ok) { failed[ci] = 1; return; }
-        chunks[ci] += hg.nchunks; evals[ci] += hg.total_evals;
+          HostPattern hp;
+          HostGather hg;
+          std::string err;
+          if (build_host_pattern(nloc, (int)(lconn.size() / 4), 4, lconn.data(), hp, err) == 0)
+            build_host_gather(nloc, (int)(lconn.size() / 4), lconn.data(), hp, 0, block, hg);
+          for (int g : touched) local[g] = -1;
+          if (!hg.ok) { failed[ci] = 1; break; }
+          chunks[ci] += hg.nchunks; evals[ci] += hg.total_evals;
+        }
       }
     });
   for (auto &x : th) x.join();
