@@ -453,6 +453,28 @@ def main():
             s10.close()
         except Exception as e:                      # noqa: BLE001
             tet10 = {"failed": str(e)}
+    # ---- the extension element that rides the same templates: 8-node bricks / 8 Gauss points (40 x 240 x 40 bricks,
+    # 384 000 elements), measured the same way
+    hex8 = None
+    if world == 1 and not args.quadratic and not args.hex and not args.no_tet10:
+        try:
+            d8 = mesh.bar_deck(n=40, hexa=True, recipe="clamped", model=model)
+            s8 = feahip.FeaSolver(d8, device=local)
+            s8.set_nodes(mesh.deformed_state(d8.nodes))
+            s8.create_stiffness_and_residual(); s8.sync()
+            z8 = s8.sizes()
+            for _ in range(50):
+                s8.create_stiffness_and_residual()
+            s8.sync()
+            ms8 = s8.time_kernel(0, warmup=10, iters=20)
+            B8 = algorithmic_bytes(8, z8["E"], z8["N"], z8["nnzb"] * 9)
+            hex8 = {"workload": f"{z8['E']} HEX8/8GP {args.model} block (40x240x40 bricks), stiffness+residual, caller numbering lexicographic",
+                    "assembly_ms": ms8, "elements_per_s": z8["E"] / (ms8 * 1e-3), "algorithmic_GBps": B8 / (ms8 * 1e-3) / 1e9,
+                    "hbm_frac": B8 / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "kernel": "k_state10<8> + k_assemble_gather10<8>" if s8.assembly_in_use() == feahip.ASM_GATHER else str(s8.assembly_in_use())}
+            s8.close()
+        except Exception as e:                      # noqa: BLE001
+            hex8 = {"failed": str(e)}
     # ---- off the lattice: (i) the SAME block with every node displaced by a deterministic
     # pseudo-random +-0.2 spacings (0.3 inverts Kuhn tetrahedra) and the caller's ids randomly permuted; (ii) the
     # reference's TetGen deck brick_fine.sexp (22 934 TET10, deck order kept as sexp_loader.c:170-215 does), 48 copies
@@ -512,6 +534,8 @@ def main():
         extras["off_lattice"] = off
     if tet10 is not None:
         extras["tet10"] = tet10
+    if hex8 is not None:
+        extras["hex8"] = hex8
     out = {
         "metric": "element-stiffness assemblies/sec", "value": value, "unit": "elements/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
